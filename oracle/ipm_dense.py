@@ -1,0 +1,507 @@
+"""ORACLE (test infrastructure, never on the product path): dense numpy specification
+of the elastic primal-dual interior-point method used for the OBCA NLP.
+
+The reference hands the NLP to IPOPT through CasADi's Opti
+(/root/reference/src/obca.py:1044-1056, 1538-1550, 1745-1746).  IPOPT itself is
+not available in the build container, and the reference's
+cold start (all variables 0, Topt 1; src/obca.py:856) is a point where the
+terminal-constraint Jacobian is rank deficient (v = 0), from which a plain
+Newton/filter IPM without IPOPT's feasibility-restoration phase stalls.  This
+file therefore restates IPOPT's published algorithm (Waechter & Biegler, Math.
+Prog. 106, 2006; option defaults of IPOPT 3.12-3.14) applied to the *elastic*
+form of the NLP -- the same l1 relaxation IPOPT's own restoration phase solves,
+kept on throughout with the true objective:
+
+    min f(x) + rho * sum_r (p_r + n_r)
+    s.t. c_h(x) = 0                          hard rows: initial state, dynamics, rotation equalities
+         g_r(x) - s_r - p_r + n_r = 0        elastic rows: every inequality and the terminal equalities
+         L_r <= s_r <= U_r,  p_r, n_r >= 0   (terminal equalities: s_r == 0)
+
+Opti poses every inequality -- simple bounds included -- as a general
+constraint, so all of them are rows here; decision variables are free.  With
+rho above the multiplier norm the elastic problem has the NLP's KKT points with
+p = n = 0 (exact penalty); a converged point with p + n > 0 is reported
+infeasible, which is what the reference's ``feas=False`` means.
+
+Kept from IPOPT: monotone barrier update (mu_init 0.1, kappa_mu 0.2, theta_mu
+1.5, kappa_eps 10), fraction-to-boundary tau = max(0.99, 1-mu), slack/bound push
+1e-2, filter line search with second-order correction, inertia-correcting
+delta_w ladder, dual reset (kappa_sigma 1e10), scaled optimality error (s_max
+100), gradient-based objective scaling (max gradient 100), tol 1e-8,
+acceptable-point logic with the reference's options for mpc6/mpc8.
+
+PARITY UNPINNED at the solver boundary: there is no IPOPT output to compare
+with.  What pins this file: (1) the NLP functions are pinned to the reference's
+model code (tests/test_oracle_nlp.py); (2) KKT certificates on the ORIGINAL NLP
+and the independent known answers of SURVEY.md Appendix C
+(tests/test_oracle_ipm.py).
+
+This dense version is the readable specification; oracle/obca_oracle.c is the
+same algorithm in C (the CPU baseline); the HIP kernel is checked against both.
+"""
+import numpy as np
+import scipy.linalg
+
+STATUS_OK = 0
+STATUS_ACCEPTABLE = 1
+STATUS_INFEASIBLE = 2          # converged, but elastic variables did not vanish
+STATUS_MAXITER = -1
+STATUS_LINESEARCH = -2
+STATUS_NUMERIC = -3
+STATUS_BAD_BOUNDS = -4
+
+DEFAULTS = dict(
+    tol=1e-8, max_iter=3000, acceptable_tol=1e-6, acceptable_iter=15,
+    acceptable_constr_viol_tol=1e-2, acceptable_dual_inf_tol=1e10, acceptable_compl_inf_tol=1e-2,
+    acceptable_obj_change_tol=1e20,
+    dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,
+    mu_init=0.1, kappa_mu=0.2, theta_mu=1.5, kappa_eps=10.0, tau_min=0.99,
+    bound_push=1e-2, bound_frac=1e-2, kappa_d=1e-5, kappa_sigma=1e10, s_max=100.0,
+    gamma_theta=1e-5, gamma_phi=1e-8, delta=1.0, s_theta=1.1, s_phi=2.3, eta_phi=1e-8, gamma_alpha=0.05,
+    kappa_soc=0.99, max_soc=4, theta_max_fact=1e4, theta_min_fact=1e-4,
+    delta_w_min=1e-20, delta_w_0=1e-4, delta_w_max=1e40, kappa_w_plus=8.0,
+    kappa_w_plus_bar=100.0, kappa_w_minus=1.0 / 3.0,
+    nlp_scaling_max_gradient=100.0,
+    rho=1e4, feas_tol=1e-6,
+)
+
+
+def options_for(variant):
+    o = dict(DEFAULTS)
+    if variant in (6, 8):   # src/obca.py:1538-1539, 1734-1735
+        o.update(max_iter=1000, acceptable_tol=1e-8, acceptable_obj_change_tol=1e-6)
+    return o
+
+
+HARD_KINDS = ('rot',)
+
+
+class Result:
+    pass
+
+
+def _ldl_inertia(K):
+    """(#positive, #negative) eigenvalues from a Bunch-Kaufman LDL^T."""
+    _, D, _ = scipy.linalg.ldl(K, lower=True)
+    n = D.shape[0]
+    pos = neg = 0
+    i = 0
+    while i < n:
+        if i + 1 < n and D[i + 1, i] != 0.0:
+            a, b, c = D[i, i], D[i + 1, i], D[i + 1, i + 1]
+            det = a * c - b * b
+            tr = a + c
+            if det < 0:
+                pos += 1
+                neg += 1
+            elif tr > 0:
+                pos += 2
+            else:
+                neg += 2
+            i += 2
+        else:
+            if D[i, i] > 0:
+                pos += 1
+            elif D[i, i] < 0:
+                neg += 1
+            i += 1
+    return pos, neg
+
+
+def split_rows(p):
+    """hard equality rows (init, dyn, rot) and elastic rows (terminal equalities + all inequalities)"""
+    lay = p.eq_layout()
+    kinds = HARD_KINDS
+    hard = np.array([i for i, r in enumerate(lay) if r[0] in kinds], dtype=int)
+    term = np.array([i for i, r in enumerate(lay) if r[0] not in kinds], dtype=int)
+    return hard, term
+
+
+def solve(p, opts=None, trace=None):
+    o = options_for(p.variant)
+    if opts:
+        o.update(opts)
+    n = p.n
+    x = p.start_point()
+    hard, term = split_rows(p)
+    lbI, ubI = p.ineq_bounds()
+    nt = term.size
+    # elastic rows: terminal equalities first (no slack), then the inequalities
+    lb = np.concatenate([np.zeros(nt), lbI])
+    ub = np.concatenate([np.zeros(nt), ubI])
+    iseq = np.concatenate([np.ones(nt, bool), np.zeros(lbI.size, bool)])
+    hasL = np.isfinite(lb) & ~iseq
+    hasU = np.isfinite(ub) & ~iseq
+    res = Result()
+    if np.any(lb[hasL & hasU] >= ub[hasL & hasU]):
+        res.status, res.iters, res.x = STATUS_BAD_BOUNDS, 0, x
+        xs, us = p.unpack_xu(x)
+        res.xopt, res.uopt, res.Ts_opt, res.feas = xs, us, p.Ts, False
+        return res
+    me = lb.size
+    mh = hard.size
+    onlyL = hasL & ~hasU
+    onlyU = hasU & ~hasL
+    kd = o["kappa_d"]
+
+    g0 = p.objective(x, grad=True)[1]
+    # IPOPT's gradient-based scaling applied to the elastic objective f + rho*sum(p+n): its gradient holds rho
+    gmax = max(np.max(np.abs(g0)), o["rho"])
+    sf = o["nlp_scaling_max_gradient"] / gmax if gmax > o["nlp_scaling_max_gradient"] else 1.0
+    rho = o["rho"] * sf
+
+    def rows(x, jac=False):
+        """hard residuals ch, elastic row functions ge (and Jacobians)"""
+        if jac:
+            c, Jc = p.eq(x, jac=True)
+            d, Jd = p.ineq(x, jac=True)
+            return c[hard], np.concatenate([c[term], d]), Jc[hard], np.vstack([Jc[term], Jd])
+        c = p.eq(x)
+        d = p.ineq(x)
+        return c[hard], np.concatenate([c[term], d])
+
+    def evals(x):
+        f, g = p.objective(x, grad=True)
+        ch, ge, Jh, Je = rows(x, jac=True)
+        return sf * f, sf * g, ch, ge, Jh, Je
+
+    f, g, ch, ge, Jh, Je = evals(x)
+    # slacks with bound push
+    s = ge.copy()
+    k1, k2 = o["bound_push"], o["bound_frac"]
+    for i in range(me):
+        if iseq[i]:
+            s[i] = 0.0
+        elif hasL[i] and hasU[i]:
+            pL = min(k1 * max(1.0, abs(lb[i])), k2 * (ub[i] - lb[i]))
+            pU = min(k1 * max(1.0, abs(ub[i])), k2 * (ub[i] - lb[i]))
+            s[i] = min(max(s[i], lb[i] + pL), ub[i] - pU)
+        elif hasL[i]:
+            s[i] = max(s[i], lb[i] + k1 * max(1.0, abs(lb[i])))
+        elif hasU[i]:
+            s[i] = min(s[i], ub[i] - k1 * max(1.0, abs(ub[i])))
+    mu = o["mu_init"]
+    # elastic variables on the central path of their own 1-d problem (IPOPT restoration initialisation)
+    r = ge - s
+    a = (mu - rho * r) / (2 * rho)
+    en = a + np.sqrt(a * a + mu * r / (2 * rho))
+    ep = r + en
+    zp = mu / ep
+    zn = mu / en
+    ye = rho - zp
+    yh = np.zeros(mh)
+    zL = np.where(hasL, 1.0, 0.0)
+    zU = np.where(hasU, 1.0, 0.0)
+    nz = int(np.sum(hasL) + np.sum(hasU)) + 2 * me
+
+    def barrier(f, s, ep, en, mu):
+        v = f + rho * (np.sum(ep) + np.sum(en)) - mu * (np.sum(np.log(ep)) + np.sum(np.log(en)))
+        v -= mu * np.sum(np.log(s[hasL] - lb[hasL]))
+        v -= mu * np.sum(np.log(ub[hasU] - s[hasU]))
+        v += kd * mu * (np.sum(s[onlyL] - lb[onlyL]) + np.sum(ub[onlyU] - s[onlyU]))
+        return v
+
+    def theta_of(ch, ge, s, ep, en):
+        return np.sum(np.abs(ch)) + np.sum(np.abs(ge - s - ep + en))
+
+    def errors(g, ch, ge, Jh, Je, s, ep, en, yh, ye, zL, zU, zp, zn, mu):
+        rx = g + Jh.T @ yh + Je.T @ ye
+        rs = np.where(iseq, 0.0, -ye - zL + zU)
+        rp = rho - ye - zp
+        rn = rho + ye - zn
+        dual = max(np.max(np.abs(rx)), np.max(np.abs(rs)), np.max(np.abs(rp)), np.max(np.abs(rn)))
+        prim = max(np.max(np.abs(ch)) if mh else 0.0, np.max(np.abs(ge - s - ep + en)))
+        comp = max(np.max(np.abs(ep * zp - mu)), np.max(np.abs(en * zn - mu)))
+        if np.any(hasL):
+            comp = max(comp, np.max(np.abs((s[hasL] - lb[hasL]) * zL[hasL] - mu)))
+        if np.any(hasU):
+            comp = max(comp, np.max(np.abs((ub[hasU] - s[hasU]) * zU[hasU] - mu)))
+        zsum = np.sum(zL) + np.sum(zU) + np.sum(zp) + np.sum(zn)
+        sd = max(o["s_max"], (np.sum(np.abs(yh)) + np.sum(np.abs(ye)) + zsum) / (mh + me + nz)) / o["s_max"]
+        sc = max(o["s_max"], zsum / nz) / o["s_max"]
+        return max(dual / sd, prim, comp / sc), dual, prim, comp
+
+    filt = []
+    th0 = theta_of(ch, ge, s, ep, en)
+    theta_max = o["theta_max_fact"] * max(1.0, th0)
+    theta_min = o["theta_min_fact"] * max(1.0, th0)
+    delta_w_last = 0.0
+    tau = max(o["tau_min"], 1.0 - mu)
+    acc_count = 0
+    f_prev = None
+    status = STATUS_MAXITER
+    nfact = 0
+    it = 0
+    E0 = np.inf
+    for it in range(o["max_iter"] + 1):
+        E0, dual, prim, comp = errors(g, ch, ge, Jh, Je, s, ep, en, yh, ye, zL, zU, zp, zn, 0.0)
+        if trace is not None:
+            trace.append(dict(it=it, f=f / sf, E0=E0, dual=dual, prim=prim, comp=comp, mu=mu, x=x.copy(),
+                              dw=delta_w_last, pn=float(np.max(ep + en))))
+        if E0 <= o["tol"] and dual <= o["dual_inf_tol"] and prim <= o["constr_viol_tol"] \
+                and comp <= o["compl_inf_tol"]:
+            status = STATUS_OK
+            break
+        fobj = f + rho * (np.sum(ep) + np.sum(en))
+        objchg = abs(fobj - f_prev) / max(1.0, abs(fobj)) if f_prev is not None else np.inf
+        if E0 <= o["acceptable_tol"] and dual <= o["acceptable_dual_inf_tol"] and \
+                prim <= o["acceptable_constr_viol_tol"] and comp <= o["acceptable_compl_inf_tol"] and \
+                objchg <= o["acceptable_obj_change_tol"]:
+            acc_count += 1
+            if acc_count >= o["acceptable_iter"]:
+                status = STATUS_ACCEPTABLE
+                break
+        else:
+            acc_count = 0
+        if it == o["max_iter"]:
+            break
+        # barrier parameter update (monotone, possibly several decreases at once)
+        mu_floor = o["tol"] / (o["kappa_eps"] + 1.0)
+        while mu > mu_floor:
+            Emu = errors(g, ch, ge, Jh, Je, s, ep, en, yh, ye, zL, zU, zp, zn, mu)[0]
+            if Emu > o["kappa_eps"] * mu:
+                break
+            mu = max(mu_floor, min(o["kappa_mu"] * mu, mu ** o["theta_mu"]))
+            tau = max(o["tau_min"], 1.0 - mu)
+            filt = []
+        # ---- search direction ---------------------------------------------------
+        c_all = np.zeros(len(p.eq_layout()))
+        c_all[hard] = yh
+        c_all[term] = ye[:nt]
+        W = sf * p.objective(x, hess=True)[1] + p.eq(x, hess_y=c_all)[1] + p.ineq(x, hess_y=ye[nt:])[1]
+        sL = np.where(hasL, s - lb, 1.0)
+        sU = np.where(hasU, ub - s, 1.0)
+        Sig_s = np.where(hasL, zL / sL, 0.0) + np.where(hasU, zU / sU, 0.0)
+        Sig_p = zp / ep
+        Sig_n = zn / en
+        gs = -np.where(hasL, mu / sL, 0.0) + np.where(hasU, mu / sU, 0.0) + kd * mu * (onlyL * 1.0 - onlyU * 1.0)
+        r_s = np.where(iseq, 0.0, -ye + gs)
+        r_p = rho - ye - mu / ep
+        r_n = rho + ye - mu / en
+        r_x = g + Jh.T @ yh + Je.T @ ye
+        r_g = ge - s - ep + en
+        cond = ~iseq                      # rows condensed into the Hessian; terminal rows stay bordered
+
+        def build(delta_w, rg_rhs, ch_rhs):
+            Ds = Sig_s + delta_w
+            Dp = Sig_p + delta_w
+            Dn = Sig_n + delta_w
+            E = np.where(iseq, 0.0, 1.0 / np.where(iseq, 1.0, Ds)) + 1.0 / Dp + 1.0 / Dn
+            ghat = rg_rhs + np.where(iseq, 0.0, r_s / np.where(iseq, 1.0, Ds)) + r_p / Dp - r_n / Dn
+            H = W + delta_w * np.eye(n)
+            if p.variant == 4:            # the N+1 tied Topt copies each carry delta_w
+                H[n - 1, n - 1] += delta_w * p.N
+            Jc_ = Je[cond]
+            H = H + Jc_.T @ (Jc_ / E[cond][:, None])
+            rhs_x = -(r_x + Jc_.T @ (ghat[cond] / E[cond]))
+            Jt = Je[iseq]
+            K = np.zeros((n + mh + nt, n + mh + nt))
+            K[:n, :n] = H
+            K[:n, n:n + mh] = Jh.T
+            K[n:n + mh, :n] = Jh
+            K[:n, n + mh:] = Jt.T
+            K[n + mh:, :n] = Jt
+            K[n + mh:, n + mh:] = -np.diag(E[iseq])
+            rhs = np.concatenate([rhs_x, -ch_rhs, -ghat[iseq]])
+            return K, rhs, (Ds, Dp, Dn, E, ghat)
+
+        def back(K, rhs, aux):
+            Ds, Dp, Dn, E, ghat = aux
+            sol = np.linalg.solve(K, rhs)
+            dx = sol[:n]
+            dyh = sol[n:n + mh]
+            dye = (Je @ dx + ghat) / E
+            dye[iseq] = sol[n + mh:]
+            ds = np.where(iseq, 0.0, (dye - r_s) / np.where(iseq, 1.0, Ds))
+            dp = (dye - r_p) / Dp
+            dn = (-dye - r_n) / Dn
+            return dx, ds, dp, dn, dyh, dye
+
+        delta_w = 0.0
+        K, rhs, aux = build(0.0, r_g, ch)
+        pos, neg = _ldl_inertia(K)
+        nfact += 1
+        if not (pos == n and neg == mh + nt):
+            delta_w = o["delta_w_0"] if delta_w_last == 0.0 else max(o["delta_w_min"],
+                                                                      o["kappa_w_minus"] * delta_w_last)
+            while True:
+                K, rhs, aux = build(delta_w, r_g, ch)
+                pos, neg = _ldl_inertia(K)
+                nfact += 1
+                if pos == n and neg == mh + nt:
+                    break
+                delta_w *= o["kappa_w_plus_bar"] if delta_w_last == 0.0 else o["kappa_w_plus"]
+                if delta_w > o["delta_w_max"]:
+                    status = STATUS_NUMERIC
+                    break
+            if status == STATUS_NUMERIC:
+                break
+            delta_w_last = delta_w
+        dx, ds, dp, dn, dyh, dye = back(K, rhs, aux)
+        dzL = np.where(hasL, (mu - zL * ds) / sL - zL, 0.0)
+        dzU = np.where(hasU, (mu + zU * ds) / sU - zU, 0.0)
+        dzp = (mu - zp * dp) / ep - zp
+        dzn = (mu - zn * dn) / en - zn
+
+        def ftb(vals, steps, mask=None):
+            m = steps < 0
+            if mask is not None:
+                m = m & mask
+            return np.min(-tau * vals[m] / steps[m]) if np.any(m) else 1.0
+
+        def ftb_primal(ds_, dp_, dn_):
+            return min(1.0, ftb(sL, ds_, hasL), ftb(sU, -ds_, hasU), ftb(ep, dp_), ftb(en, dn_))
+
+        a_max = ftb_primal(ds, dp, dn)
+        if o.get("verbose", 0) > 1:
+            names = [("term", i) for i in range(nt)] + p.ineq_layout()
+            for nm, vals, steps, mask in (("sL", sL, ds, hasL), ("sU", sU, -ds, hasU), ("p", ep, dp, None), ("n", en, dn, None)):
+                m = steps < 0
+                if mask is not None:
+                    m = m & mask
+                if np.any(m):
+                    rat = np.where(m, -tau * vals / np.where(m, steps, -1.0), np.inf)
+                    i = int(np.argmin(rat))
+                    print("    ftb %s: row %s val %.3e step %.3e ratio %.3e" % (nm, names[i], vals[i], steps[i], rat[i]))
+        a_z = min(1.0, ftb(zL, dzL, hasL), ftb(zU, dzU, hasU), ftb(zp, dzp), ftb(zn, dzn))
+
+        # ---- filter line search ------------------------------------------------
+        th = theta_of(ch, ge, s, ep, en)
+        phi = barrier(f, s, ep, en, mu)
+        dphi = g @ dx + gs @ ds + (rho - mu / ep) @ dp + (rho - mu / en) @ dn
+        if dphi < 0:
+            cand = [o["gamma_theta"], o["gamma_phi"] * th / (-dphi)]
+            if th <= theta_min:
+                cand.append(o["delta"] * th ** o["s_theta"] / (-dphi) ** o["s_phi"])
+            alpha_min = o["gamma_alpha"] * min(cand)
+        else:
+            alpha_min = o["gamma_alpha"] * o["gamma_theta"]
+
+        def in_filter(th_t, phi_t):
+            if th_t >= theta_max:
+                return True
+            return any(th_t >= tf and phi_t >= pf for (tf, pf) in filt)
+
+        def acceptable(alpha, th_t, phi_t):
+            if not np.isfinite(phi_t) or in_filter(th_t, phi_t):
+                return False, False
+            switching = dphi < 0 and alpha * (-dphi) ** o["s_phi"] > o["delta"] * th ** o["s_theta"]
+            if th <= theta_min and switching:
+                return (phi_t <= phi + o["eta_phi"] * alpha * dphi + 10 * np.finfo(float).eps * abs(phi)), False
+            return (th_t <= (1 - o["gamma_theta"]) * th or phi_t <= phi - o["gamma_phi"] * th), True
+
+        def trial(alpha, dx_, ds_, dp_, dn_):
+            xt = x + alpha * dx_
+            st = s + alpha * ds_
+            pt = ep + alpha * dp_
+            nt_ = en + alpha * dn_
+            ft = sf * p.objective(xt)
+            cht, get = rows(xt)
+            if not (np.isfinite(ft) and np.all(np.isfinite(cht)) and np.all(np.isfinite(get))):
+                return (xt, st, pt, nt_), np.inf, np.inf, None
+            return (xt, st, pt, nt_), theta_of(cht, get, st, pt, nt_), barrier(ft, st, pt, nt_, mu), (cht, get)
+
+        alpha = a_max
+        accepted = False
+        first_trial = True
+        aug = False
+        step = None
+        while True:
+            pt_, th_t, phi_t, ev = trial(alpha, dx, ds, dp, dn)
+            ok_, aug = acceptable(alpha, th_t, phi_t)
+            if ok_:
+                accepted = True
+                step = (alpha, dx, ds, dp, dn, dyh, dye)
+                break
+            if first_trial and th_t >= th and ev is not None:
+                # second-order correction
+                c_soc = alpha * ch + ev[0]
+                g_soc = alpha * r_g + (ev[1] - pt_[1] - pt_[2] + pt_[3])
+                th_old = th_t
+                for _ in range(o["max_soc"]):
+                    Ks, rs_, auxs = build(delta_w, g_soc, c_soc)
+                    dxs, dss, dps, dns, dyhs, dyes = back(Ks, rs_, auxs)
+                    a_soc = ftb_primal(dss, dps, dns)
+                    pts, th_s, phi_s, evs = trial(a_soc, dxs, dss, dps, dns)
+                    ok_s, aug_s = acceptable(alpha, th_s, phi_s)
+                    if ok_s:
+                        accepted = True
+                        pt_, th_t, phi_t, ev, aug = pts, th_s, phi_s, evs, aug_s
+                        step = (a_soc, dxs, dss, dps, dns, dyhs, dyes)
+                        break
+                    if evs is None or th_s > o["kappa_soc"] * th_old:
+                        break
+                    th_old = th_s
+                    c_soc = a_soc * c_soc + evs[0]
+                    g_soc = a_soc * g_soc + (evs[1] - pts[1] - pts[2] + pts[3])
+                if accepted:
+                    break
+            first_trial = False
+            alpha *= 0.5
+            if alpha < alpha_min:
+                break
+        if o.get("verbose"):
+            print("it %3d f %.6e pn %.2e th %.2e phi %.6e dphi %.2e mu %.1e dw %.1e a %.2e az %.2e |dx| %.2e E0 %.2e %s"
+                  % (it, f / sf, np.max(ep + en), th, phi, dphi, mu, delta_w, step[0] if accepted else -1, a_z,
+                     np.max(np.abs(dx)), E0, "" if accepted else "LS-FAIL"))
+        if not accepted:
+            status = STATUS_LINESEARCH
+            break
+        if aug:
+            tn, pn_ = (1 - o["gamma_theta"]) * th, phi - o["gamma_phi"] * th
+            filt = [(tf, pf) for (tf, pf) in filt if not (tf >= tn and pf >= pn_)]   # drop dominated entries
+            filt.append((tn, pn_))
+            res.max_filter = max(getattr(res, "max_filter", 0), len(filt))
+        a_used = step[0]
+        f_prev = fobj
+        x, s, ep, en = pt_
+        yh = yh + a_used * step[5]
+        ye = ye + a_used * step[6]
+        zL = zL + a_z * dzL
+        zU = zU + a_z * dzU
+        zp = zp + a_z * dzp
+        zn = zn + a_z * dzn
+        sL = np.where(hasL, s - lb, 1.0)
+        sU = np.where(hasU, ub - s, 1.0)
+        ks = o["kappa_sigma"]
+        zL = np.where(hasL, np.maximum(np.minimum(zL, ks * mu / sL), mu / (ks * sL)), 0.0)
+        zU = np.where(hasU, np.maximum(np.minimum(zU, ks * mu / sU), mu / (ks * sU)), 0.0)
+        zp = np.maximum(np.minimum(zp, ks * mu / ep), mu / (ks * ep))
+        zn = np.maximum(np.minimum(zn, ks * mu / en), mu / (ks * en))
+        f, g, ch, ge, Jh, Je = evals(x)
+    res.iters = it
+    res.nfact = nfact
+    res.x = x
+    res.f = p.objective(x)
+    res.mu = mu
+    res.E0 = E0
+    res.elastic = float(np.max(ep + en))
+    res.yh, res.ye = yh / sf, ye / sf
+    if status in (STATUS_OK, STATUS_ACCEPTABLE) and res.elastic > o["feas_tol"]:
+        status = STATUS_INFEASIBLE
+    res.status = status
+    res.feas = status in (STATUS_OK, STATUS_ACCEPTABLE)
+    xs, us = p.unpack_xu(x)
+    res.xopt, res.uopt = xs, us
+    res.Ts_opt = (x[p.iT()] * p.Ts) if p.variant == 4 else p.Ts
+    return res
+
+
+def kkt_certificate(p, res):
+    """Residuals of the ORIGINAL NLP's first-order conditions at res (multipliers from the elastic solve)."""
+    hard, term = split_rows(p)
+    x = res.x
+    g = p.objective(x, grad=True)[1]
+    c, Jc = p.eq(x, jac=True)
+    d, Jd = p.ineq(x, jac=True)
+    lb, ub = p.ineq_bounds()
+    y = np.zeros(c.size)
+    y[hard] = res.yh
+    y[term] = res.ye[:term.size]
+    yd = res.ye[term.size:]
+    stat = np.max(np.abs(g + Jc.T @ y + Jd.T @ yd))
+    prim = max(np.max(np.abs(c)), np.max(np.maximum(lb - d, 0.0)), np.max(np.maximum(d - ub, 0.0)))
+    slackL = np.where(np.isfinite(lb), d - lb, np.inf)
+    slackU = np.where(np.isfinite(ub), ub - d, np.inf)
+    comp = np.max(np.abs(yd) * np.minimum(slackL, slackU))
+    return dict(stationarity=float(stat), primal=float(prim), complementarity=float(comp))
