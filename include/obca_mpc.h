@@ -1,0 +1,116 @@
+/*
+ * obca_mpc.h -- C ABI of the MI355X batched OBCA-MPC solver (libobca_mpc.so).
+ *
+ * Drop-in boundary.  The reference has no FFI: the hot path is entered through plain Python method
+ * calls on `obca()` (reference src/closed_loop.py:22, call sites :117-120, :130-140, :381-398).  Each
+ * entry point below therefore names the reference interface it stands behind:
+ *
+ *   obca_create / obca_destroy   construction of the solver object   (src/closed_loop.py:22  `obca()`)
+ *   obca_solve_batch             obca.obca_mpc4 / obca_mpc6 / obca_mpc8 (src/obca.py:828, :1361, :1564),
+ *                                B independent calls at once
+ *   obca_strerror                the reference never raises across this boundary (bare `except:`,
+ *                                src/obca.py:1062-1065); errors are return codes / per-instance status
+ *
+ * All array arguments are DEVICE pointers (HBM resident, e.g. torch `data_ptr()`), row-major, fp64
+ * unless noted; the caller owns every buffer.  Calls are asynchronous on the given HIP stream.
+ * No C++ exception crosses this boundary.
+ */
+#ifndef OBCA_MPC_H
+#define OBCA_MPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBCA_MAX_OBST 8      /* obstacles per instance                               */
+#define OBCA_MAX_EDGES 4     /* half-spaces per obstacle (vObs[i]-1 in the reference) */
+
+/* problem shape shared by every instance of a handle (reference arguments N, nObs, vObs) */
+typedef struct obca_dims {
+    int32_t N;                         /* horizon (reference argument N)                          */
+    int32_t n_obs;                     /* obstacles passed to the solver (reference nObs)         */
+    int32_t m[OBCA_MAX_OBST];          /* half-spaces of obstacle i = vObs[i]-1                   */
+    int32_t max_batch;                 /* largest B later passed to obca_solve_batch              */
+    int32_t device;                    /* HIP device ordinal                                      */
+} obca_dims;
+
+/* cost weights of one call family (reference arguments P, Q, R=[R1,R2]) */
+typedef struct obca_weights {
+    double Q[9], P[9], R1[4], R2[4];
+} obca_weights;
+
+/* everything else the reference passes per call and keeps constant over a rollout */
+typedef struct obca_params {
+    obca_weights free_time;            /* used by variant 4 (closed_loop.py:77-81)                */
+    obca_weights fixed_time;           /* used by variants 6 and 8 (closed_loop.py:94-98)         */
+    double xL[2], xU[2];               /* position box (theta is unbounded, obca.py:916)          */
+    double uL[2], uU[2];               /* input box                                               */
+    double ego[4];                     /* car footprint (closed_loop.py:63)                       */
+    double dmin;                       /* clearance (closed_loop.py:64)                           */
+    /* interior-point options; <= 0 selects the default in brackets */
+    double tol;                        /* [1e-8]  IPOPT tol                                        */
+    double rho;                        /* [1e4]   elastic (l1) penalty, unscaled objective units   */
+    double feas_tol;                   /* [1e-6]  largest elastic variable still called feasible   */
+    int32_t max_iter_free;             /* [3000]  IPOPT default, variant 4                         */
+    int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8                       */
+} obca_params;
+
+typedef struct obca_handle obca_handle;
+
+/* per-instance status written by obca_solve_batch */
+enum {
+    OBCA_STATUS_OK = 0,                /* converged to tol                                        */
+    OBCA_STATUS_ACCEPTABLE = 1,        /* IPOPT "acceptable" termination                          */
+    OBCA_STATUS_INFEASIBLE = 2,        /* converged but elastic variables remain (feas = False)   */
+    OBCA_STATUS_MAXITER = -1,
+    OBCA_STATUS_LINESEARCH = -2,
+    OBCA_STATUS_NUMERIC = -3,
+    OBCA_STATUS_BAD_BOUNDS = -4
+};
+
+/* return codes */
+enum {
+    OBCA_OK = 0,
+    OBCA_E_INVAL = -22,                /* bad argument / shape beyond compiled limits             */
+    OBCA_E_NOMEM = -12,
+    OBCA_E_HIP = -5,                   /* a HIP runtime call failed                               */
+    OBCA_E_LDS = -28                   /* instance does not fit the 160 KiB LDS of one CU         */
+};
+
+int obca_create(const obca_dims* dims, obca_handle** out);
+void obca_destroy(obca_handle* h);
+
+/*
+ * Solve B independent NLPs.  variant[b] in {4, 6, 8} selects obca_mpc4 / obca_mpc6 / obca_mpc8.
+ *   x0    [B,3]          current pose                     (reference x0)
+ *   u0    [B,2]          previous input                   (reference u0)
+ *   xref  [B,3,N+1]      reference window                 (reference xref[:, :N+1])
+ *   A     [B,N+1,M,2]    obstacle rows per horizon step   (reference AObs; variant 4 reads step 0 only,
+ *   b     [B,N+1,M]       obca.py:969; M = sum m[i])      (reference bObs)
+ *   Ts    [B]            base sample time                 (reference Ts)
+ *   term  [B,3]          xmin, ymin, ymax of the terminal set, variant 6 only (obca.py:1465-1466)
+ * outputs
+ *   xopt  [B,3,N+1], uopt [B,2,N], ts_opt [B] (= Topt*Ts for variant 4, Ts otherwise)
+ *   status [B] int32, iters [B] int32
+ *   info  [B,4] or NULL: objective value, largest elastic variable, final optimality error,
+ *                        number of KKT factorisations
+ */
+int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
+                     const double* x0, const double* u0, const double* xref,
+                     const double* A, const double* b, const double* Ts, const double* term,
+                     const obca_params* params,
+                     double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
+                     double* info, void* hip_stream);
+
+/* bytes of LDS one instance needs with these dims (<= 163840 or obca_create fails with OBCA_E_LDS) */
+int64_t obca_lds_bytes(const obca_dims* dims);
+
+const char* obca_strerror(int code);
+const char* obca_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

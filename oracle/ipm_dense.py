@@ -338,6 +338,9 @@ def solve(p, opts=None, trace=None):
                 break
             delta_w_last = delta_w
         dx, ds, dp, dn, dyh, dye = back(K, rhs, aux)
+        if o.get("probe") is not None:
+            o["probe"](dict(it=it, W=W, Je=Je, Jh=Jh, E=aux[3], ghat=aux[4], r_x=r_x, ch=ch, iseq=iseq, dx=dx,
+                            dyh=dyh, dye=dye, delta_w=delta_w, hard=hard, term=term, mu=mu))
         dzL = np.where(hasL, (mu - zL * ds) / sL - zL, 0.0)
         dzU = np.where(hasU, (mu + zU * ds) / sU - zU, 0.0)
         dzp = (mu - zp * dp) / ep - zp

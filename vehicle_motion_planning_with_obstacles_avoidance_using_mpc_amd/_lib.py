@@ -1,0 +1,72 @@
+"""ctypes binding of libobca_mpc.so (C ABI in include/obca_mpc.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is visible, loading
+or solving raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libobca_mpc.so")
+
+OBCA_MAX_OBST = 8
+OBCA_MAX_EDGES = 4
+
+
+class ObcaDims(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("n_obs", ctypes.c_int32), ("m", ctypes.c_int32 * OBCA_MAX_OBST),
+                ("max_batch", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
+class ObcaWeights(ctypes.Structure):
+    _fields_ = [("Q", ctypes.c_double * 9), ("P", ctypes.c_double * 9), ("R1", ctypes.c_double * 4),
+                ("R2", ctypes.c_double * 4)]
+
+
+class ObcaParams(ctypes.Structure):
+    _fields_ = [("free_time", ObcaWeights), ("fixed_time", ObcaWeights),
+                ("xL", ctypes.c_double * 2), ("xU", ctypes.c_double * 2),
+                ("uL", ctypes.c_double * 2), ("uU", ctypes.c_double * 2),
+                ("ego", ctypes.c_double * 4), ("dmin", ctypes.c_double),
+                ("tol", ctypes.c_double), ("rho", ctypes.c_double), ("feas_tol", ctypes.c_double),
+                ("max_iter_free", ctypes.c_int32), ("max_iter_fixed", ctypes.c_int32)]
+
+
+EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version")
+
+STATUS_OK, STATUS_ACCEPTABLE, STATUS_INFEASIBLE = 0, 1, 2
+STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NUMERIC, STATUS_BAD_BOUNDS = -1, -2, -3, -4
+
+_lib = None
+
+
+def load():
+    """Load the shared library (built by __graft_entry__.build()); raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libobca_mpc.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(expected at %s). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32p = ctypes.c_void_p, ctypes.c_void_p
+    lib.obca_create.argtypes = [ctypes.POINTER(ObcaDims), ctypes.POINTER(ctypes.c_void_p)]
+    lib.obca_create.restype = ctypes.c_int
+    lib.obca_destroy.argtypes = [ctypes.c_void_p]
+    lib.obca_destroy.restype = None
+    lib.obca_solve_batch.argtypes = [ctypes.c_void_p, i32p, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp,
+                                     ctypes.POINTER(ObcaParams), vp, vp, vp, i32p, i32p, vp, vp]
+    lib.obca_solve_batch.restype = ctypes.c_int
+    lib.obca_lds_bytes.argtypes = [ctypes.POINTER(ObcaDims)]
+    lib.obca_lds_bytes.restype = ctypes.c_int64
+    lib.obca_strerror.argtypes = [ctypes.c_int]
+    lib.obca_strerror.restype = ctypes.c_char_p
+    lib.obca_version.argtypes = []
+    lib.obca_version.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise RuntimeError("libobca_mpc: %s (code %d)" % (load().obca_strerror(code).decode(), code))

@@ -1,0 +1,147 @@
+// obca_capi.hip -- host side of libobca_mpc.so: the C ABI declared in include/obca_mpc.h.
+// Plain pointers and sizes only; every failure is a return code (no exception leaves this file).
+
+#include <hip/hip_runtime.h>
+#include <new>
+#include <stdint.h>
+#include <string.h>
+#include "obca_device.h"
+
+extern "C" __global__ void obca_ipm_kernel(ObcaLaunch A);
+
+struct obca_handle {
+    obca_dims dims;
+    int32_t M, n_max, R_max;
+    int32_t offm[OBCA_MAX_OBST + 1];
+    int64_t lds_bytes;
+};
+
+namespace {
+
+constexpr int MW = OBCA_MAX_EDGES + 6;
+
+bool dims_ok(const obca_dims* d) {
+    if (!d) return false;
+    if (d->N < 1 || d->N > 63) return false;
+    if (d->n_obs < 1 || d->n_obs > OBCA_MAX_OBST) return false;
+    for (int i = 0; i < d->n_obs; ++i)
+        if (d->m[i] < 1 || d->m[i] > OBCA_MAX_EDGES) return false;
+    return true;
+}
+
+// must mirror the carve-up in obca_kernel.hip
+int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max) {
+    const int N1 = N + 1, np = N1 * nO;
+    n_max = N1 * (3 + M + 4 * nO) + 2 * N + 1;
+    R_max = 3 + 3 * N + 3 + 2 * N1 + 2 * N + 2 * N + 2 + 2 * np + N1 * M + N1 * 4 * nO;
+    int64_t t = 0;
+    auto take = [&](int64_t c) { t += (c + 1) & ~int64_t(1); };
+    for (int i = 0; i < 6; ++i) take(n_max);
+    for (int i = 0; i < 15; ++i) take(R_max);
+    take(N1); take(N1); take(2 * np); take(N1); take(N1); take(2 * np);
+    take(2 * np); take(2 * np); take(2 * np);
+    take(N1 * M * 2); take(N1 * M); take(3 * N1);
+    take(64 * N1); take(8 * N1); take(12 * np); take(MW * 4 * np);
+    take(36 * N1); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
+    take(36); take(6); take(48); take(6); take(48); take(6); take(64); take(8); take(8);
+    return t;
+}
+
+}  // namespace
+
+extern "C" int64_t obca_lds_bytes(const obca_dims* d) {
+    if (!dims_ok(d)) return -1;
+    int M = 0;
+    for (int i = 0; i < d->n_obs; ++i) M += d->m[i];
+    int n_max, R_max;
+    return 8 * lds_doubles(d->N, d->n_obs, M, n_max, R_max);
+}
+
+extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
+    if (!out) return OBCA_E_INVAL;
+    *out = nullptr;
+    if (!dims_ok(d) || d->max_batch < 1) return OBCA_E_INVAL;
+    obca_handle* h = new (std::nothrow) obca_handle;
+    if (!h) return OBCA_E_NOMEM;
+    h->dims = *d;
+    h->M = 0;
+    h->offm[0] = 0;
+    for (int i = 0; i < OBCA_MAX_OBST; ++i) {
+        if (i < d->n_obs) h->M += d->m[i];
+        h->offm[i + 1] = h->M;
+    }
+    h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max);
+    if (h->lds_bytes > 160 * 1024) { delete h; return OBCA_E_LDS; }
+    if (hipSetDevice(d->device) != hipSuccess) { delete h; return OBCA_E_HIP; }
+    if (h->lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(obca_ipm_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+            delete h;
+            return OBCA_E_HIP;
+        }
+    }
+    *out = h;
+    return OBCA_OK;
+}
+
+extern "C" void obca_destroy(obca_handle* h) { delete h; }
+
+extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
+                                const double* x0, const double* u0, const double* xref,
+                                const double* A, const double* b, const double* Ts, const double* term,
+                                const obca_params* p,
+                                double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
+                                double* info, void* hip_stream) {
+    if (!h || !variant || !x0 || !u0 || !xref || !A || !b || !Ts || !p || !xopt || !uopt || !ts_opt || !status ||
+        !iters)
+        return OBCA_E_INVAL;
+    if (B < 0 || B > h->dims.max_batch) return OBCA_E_INVAL;
+    if (B == 0) return OBCA_OK;
+    ObcaLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.B = B; L.N = h->dims.N; L.nO = h->dims.n_obs; L.M = h->M; L.n_max = h->n_max; L.R_max = h->R_max;
+    for (int i = 0; i <= OBCA_MAX_OBST; ++i) L.offm[i] = h->offm[i];
+    L.variant = variant; L.x0 = x0; L.u0 = u0; L.xref = xref; L.A = A; L.b = b; L.Ts = Ts; L.term = term;
+    L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info;
+    auto cpw = [](ObcaWeightsDev& d, const obca_weights& s) {
+        // the reference's double loops use Q[i,j] for every (i,j): only the symmetric part matters
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                d.Q[3 * a + c] = 0.5 * (s.Q[3 * a + c] + s.Q[3 * c + a]);
+                d.P[3 * a + c] = 0.5 * (s.P[3 * a + c] + s.P[3 * c + a]);
+            }
+        for (int a = 0; a < 2; ++a)
+            for (int c = 0; c < 2; ++c) {
+                d.R1[2 * a + c] = 0.5 * (s.R1[2 * a + c] + s.R1[2 * c + a]);
+                d.R2[2 * a + c] = 0.5 * (s.R2[2 * a + c] + s.R2[2 * c + a]);
+            }
+    };
+    cpw(L.prm.free_time, p->free_time);
+    cpw(L.prm.fixed_time, p->fixed_time);
+    for (int j = 0; j < 2; ++j) { L.prm.xL[j] = p->xL[j]; L.prm.xU[j] = p->xU[j]; L.prm.uL[j] = p->uL[j]; L.prm.uU[j] = p->uU[j]; }
+    const double Lc = p->ego[0] + p->ego[2], Wc = p->ego[1] + p->ego[3];       // src/obca.py:1019-1026
+    L.prm.gego[0] = Lc / 2; L.prm.gego[1] = Wc / 2; L.prm.gego[2] = Lc / 2; L.prm.gego[3] = Wc / 2;
+    L.prm.off = Lc / 2 - p->ego[2];
+    L.prm.dmin = p->dmin;
+    L.prm.opt.tol = p->tol > 0 ? p->tol : 1e-8;
+    L.prm.opt.rho = p->rho > 0 ? p->rho : 1e4;
+    L.prm.opt.feas_tol = p->feas_tol > 0 ? p->feas_tol : 1e-6;
+    L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
+    L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
+    hipLaunchKernelGGL(obca_ipm_kernel, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+    if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
+    return OBCA_OK;
+}
+
+extern "C" const char* obca_strerror(int code) {
+    switch (code) {
+        case OBCA_OK: return "ok";
+        case OBCA_E_INVAL: return "invalid argument or shape beyond compiled limits";
+        case OBCA_E_NOMEM: return "out of host memory";
+        case OBCA_E_HIP: return "HIP runtime call failed";
+        case OBCA_E_LDS: return "instance does not fit in 160 KiB of LDS";
+        default: return "unknown error";
+    }
+}
+
+extern "C" const char* obca_version(void) { return "obca_mpc 0.1 (gfx950)"; }

@@ -1,0 +1,62 @@
+// obca_device.h -- structures shared by the HIP kernel and the host side of libobca_mpc.so.
+#ifndef OBCA_DEVICE_H
+#define OBCA_DEVICE_H
+
+#include <stdint.h>
+#include "../../include/obca_mpc.h"
+
+// reference constants
+#define OBCA_ACC_MAX0 0.6                       /* src/obca.py:932  */
+#define OBCA_ACC_MAX1 0.5235987755982988        /* pi/6, src/obca.py:933 */
+#define OBCA_T_MIN 1e-4                         /* src/obca.py:963  */
+
+// IPOPT defaults restated in oracle/ipm_dense.py (same names)
+#define OBCA_MU_INIT 0.1
+#define OBCA_KAPPA_MU 0.2
+#define OBCA_THETA_MU 1.5
+#define OBCA_KAPPA_EPS 10.0
+#define OBCA_TAU_MIN 0.99
+#define OBCA_BOUND_PUSH 1e-2
+#define OBCA_BOUND_FRAC 1e-2
+#define OBCA_KAPPA_D 1e-5
+#define OBCA_KAPPA_SIGMA 1e10
+#define OBCA_S_MAX 100.0
+#define OBCA_GAMMA_THETA 1e-5
+#define OBCA_GAMMA_PHI 1e-8
+#define OBCA_DELTA 1.0
+#define OBCA_S_THETA 1.1
+#define OBCA_S_PHI 2.3
+#define OBCA_ETA_PHI 1e-8
+#define OBCA_GAMMA_ALPHA 0.05
+#define OBCA_THETA_MAX_FACT 1e4
+#define OBCA_THETA_MIN_FACT 1e-4
+#define OBCA_DELTA_W_MIN 1e-20
+#define OBCA_DELTA_W_0 1e-4
+#define OBCA_DELTA_W_MAX 1e40
+#define OBCA_KAPPA_W_PLUS 8.0
+#define OBCA_KAPPA_W_PLUS_BAR 100.0
+#define OBCA_KAPPA_W_MINUS (1.0 / 3.0)
+#define OBCA_MAX_GRADIENT 100.0
+#define OBCA_ACCEPTABLE_ITER 15
+
+struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
+struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed; };
+struct ObcaParamsDev {
+    ObcaWeightsDev free_time, fixed_time;
+    double xL[2], xU[2], uL[2], uU[2];
+    double gego[4], off, dmin;
+    ObcaOptsDev opt;
+};
+
+struct ObcaLaunch {
+    int32_t B, N, nO, M, n_max, R_max;
+    int32_t offm[OBCA_MAX_OBST + 1];
+    const int32_t* variant;
+    const double *x0, *u0, *xref, *A, *b, *Ts, *term;
+    double *xopt, *uopt, *ts_opt;
+    int32_t *status, *iters;
+    double* info;
+    ObcaParamsDev prm;
+};
+
+#endif

@@ -1,0 +1,1395 @@
+// obca_kernel.hip -- batched OBCA-MPC interior-point solver for MI355X (gfx950, CDNA4).
+//
+// One 64-lane wavefront (= one workgroup) solves one NLP instance; every iterate, row state and KKT block
+// of that instance lives in the CU's LDS.  The algorithm is the elastic primal-dual interior-point method
+// specified in oracle/ipm_dense.py (IPOPT's filter line-search algorithm applied to the l1-elastic form of
+// the NLP that the reference builds in src/obca.py:828-1071 / 1361-1562 / 1564-1758); the Newton step is
+// the two-level structured solve of oracle/kkt_structured.py:
+//   level 1  per (stage, obstacle): LDL^T of the (lambda_i, mu_i, nu_i) block, one lane per pair, fully in
+//            registers, 3x3 Schur complement onto the pose;
+//   level 2  backward Riccati sweep over xi_k = (dp_k, du_{k-1}, dT) with the elastic dynamics rows folded in
+//            through (I + P E)^-1 P, lane-parallel over the 6x6 / 8x8 stage blocks held in LDS.
+// Nothing here calls into oracle/; the oracle is the checker (tests/, bench.py cpu_baseline).
+//
+// fp64 throughout (reference arithmetic: IPOPT/MUMPS double).  No MFMA: the largest dense block is 8x8.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "obca_device.h"
+
+#define SYNC() __syncthreads()
+
+namespace {
+
+constexpr int MW = OBCA_MAX_EDGES + 6;      // local block width: lambda (<=4) + mu (4) + nu (2)
+constexpr int NW = OBCA_MAX_EDGES + 4;      // primal part of the local block
+
+// ---------------------------------------------------------------- wave reductions (64 lanes, butterfly)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_or(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- instance layout
+struct Lay {
+    int N, nO, M, NS, n, free_T, variant;
+    int r_init, r_dyn, r_term, r_xb, r_ub, r_acc, r_T, r_tx, r_norm, r_dist, r_lam, r_mu, R;
+    int npair;
+    int offm[OBCA_MAX_OBST + 1];
+    __device__ __forceinline__ int ip(int k) const { return k * NS; }
+    __device__ __forceinline__ int iu(int k) const { return k * NS + 3; }
+    __device__ __forceinline__ int il(int k) const { return k * NS + (k < N ? 5 : 3); }
+    __device__ __forceinline__ int imu(int k) const { return il(k) + M; }
+    __device__ __forceinline__ int iT() const { return n - 1; }
+};
+
+struct Inst {             // per-instance constants (registers, wave-uniform)
+    double x0[3], u0[2], Ts, Tmax, term[3];
+    double xL[2], xU[2], uL[2], uU[2], gego[4], off, dmin;
+    double Q[9], P[9], R1[4], R2[4];
+};
+
+// LDS carve-up (all doubles)
+struct Sh {
+    double *x, *xt, *dx, *gf, *rx, *bx;
+    double *s, *p, *n, *y, *zL, *zU, *zp, *zn, *g, *Einv, *yhat, *gh, *dy, *Lb, *Ub;
+    double *ct, *st, *cc, *ctt, *stt, *cct;
+    double *nu, *dnu, *crot;
+    double *Aobs, *bobs, *xref;
+    double *Lall, *lall, *Sloc, *Y;
+    double *Pk, *qk, *Kk, *kapk, *Mik;
+    double *X, *qt, *FG, *fv, *Z, *zv, *Mall, *mall;
+    double *red;
+};
+
+__device__ __forceinline__ double dmaxabs(double a, double b) { return fmax(a, fabs(b)); }
+
+// weight of a row in sums (the N+1 tied Topt copies are one row with multiplicity N+1)
+__device__ __forceinline__ double row_w(const Lay& L, int r) {
+    return (L.free_T && r >= L.r_T && r < L.r_T + 2) ? (double)(L.N + 1) : 1.0;
+}
+__device__ __forceinline__ bool row_iseq(const Lay& L, int r) { return r < L.r_xb; }   // init, dyn, term
+__device__ __forceinline__ bool row_soft(const Lay& L, int r) { return r < L.r_term; } // init, dyn (Riccati)
+
+// ---------------------------------------------------------------- model evaluation
+// trig + c = A^T lambda for an iterate held in xv; results into ct/st/cc
+__device__ void eval_geom(const Lay& L, const Sh& S, const double* xv, double* ct, double* st, double* cc,
+                          int lane) {
+    for (int k = lane; k <= L.N; k += 64) {
+        double sn, cs;
+        sincos(xv[L.ip(k) + 2], &sn, &cs);
+        ct[k] = cs;
+        st[k] = sn;
+    }
+    for (int pr = lane; pr < L.npair; pr += 64) {
+        const int k = pr / L.nO, i = pr - k * L.nO;
+        const int o0 = L.offm[i], o1 = L.offm[i + 1];
+        const double* lam = xv + L.il(k);
+        const double* A = S.Aobs + (size_t)k * L.M * 2;
+        double c0 = 0.0, c1 = 0.0;
+        for (int j = o0; j < o1; ++j) {
+            c0 += A[2 * j] * lam[j];
+            c1 += A[2 * j + 1] * lam[j];
+        }
+        cc[2 * pr] = c0;
+        cc[2 * pr + 1] = c1;
+    }
+    SYNC();
+}
+
+// value of elastic row r at iterate xv (geometry arrays must be current)
+__device__ double row_value(const Lay& L, const Sh& S, const Inst& in, const double* xv, const double* ct,
+                            const double* st, const double* cc, int r) {
+    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double h = T * in.Ts;
+    if (r < L.r_dyn) return xv[r] - in.x0[r];
+    if (r < L.r_term) {
+        const int q = r - L.r_dyn, k = q / 3, j = q - 3 * k;
+        const double* pk = xv + L.ip(k);
+        const double* pn = xv + L.ip(k + 1);
+        const double* u = xv + L.iu(k);
+        const double f = (j == 0) ? u[0] * ct[k] : (j == 1) ? u[0] * st[k] : u[1];
+        return pn[j] - pk[j] - h * f;
+    }
+    if (r < L.r_xb) {
+        const int j = r - L.r_term;
+        return xv[L.ip(L.N) + j] - S.xref[j * (L.N + 1) + L.N];
+    }
+    if (r < L.r_ub) {
+        const int q = r - L.r_xb;
+        return xv[L.ip(q >> 1) + (q & 1)];
+    }
+    if (r < L.r_acc) {
+        const int q = r - L.r_ub;
+        return xv[L.iu(q >> 1) + (q & 1)];
+    }
+    if (r < L.r_T) {
+        const int q = r - L.r_acc, k = q >> 1, c = q & 1;
+        const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
+        return (prev - xv[L.iu(k) + c]) / h;
+    }
+    if (r < L.r_tx) return T;
+    if (r < L.r_norm) return xv[L.ip(L.N) + (r - L.r_tx)];
+    if (r < L.r_dist) {
+        const int pr = r - L.r_norm;
+        return cc[2 * pr] * cc[2 * pr] + cc[2 * pr + 1] * cc[2 * pr + 1];
+    }
+    if (r < L.r_lam) {
+        const int pr = r - L.r_dist, k = pr / L.nO, i = pr - k * L.nO;
+        const double* pk = xv + L.ip(k);
+        const double tx = pk[0] + ct[k] * in.off, ty = pk[1] + st[k] * in.off;
+        const double* mu = xv + L.imu(k) + 4 * i;
+        const double* lam = xv + L.il(k);
+        const double* b = S.bobs + (size_t)k * L.M;
+        double v = -(in.gego[0] * mu[0] + in.gego[1] * mu[1] + in.gego[2] * mu[2] + in.gego[3] * mu[3]) +
+                   tx * cc[2 * pr] + ty * cc[2 * pr + 1];
+        for (int j = L.offm[i]; j < L.offm[i + 1]; ++j) v -= b[j] * lam[j];
+        return v;
+    }
+    if (r < L.r_mu) {
+        const int q = r - L.r_lam, k = q / L.M, j = q - k * L.M;
+        return xv[L.il(k) + j];
+    }
+    {
+        const int q = r - L.r_mu, w4 = 4 * L.nO, k = q / w4, j = q - k * w4;
+        return xv[L.imu(k) + j];
+    }
+}
+
+__device__ void row_bounds(const Lay& L, const Inst& in, int r, double& lo, double& up) {
+    const double INF = INFINITY;
+    if (r < L.r_xb) { lo = 0.0; up = 0.0; return; }
+    if (r < L.r_ub) { const int j = (r - L.r_xb) & 1; lo = in.xL[j]; up = in.xU[j]; return; }
+    if (r < L.r_acc) { const int j = (r - L.r_ub) & 1; lo = in.uL[j]; up = in.uU[j]; return; }
+    if (r < L.r_T) { const int c = (r - L.r_acc) & 1; const double a = c ? OBCA_ACC_MAX1 : OBCA_ACC_MAX0; lo = -a; up = a; return; }
+    if (r < L.r_tx) { if (r == L.r_T) { lo = 0.0; up = INF; } else { lo = OBCA_T_MIN; up = in.Tmax; } return; }
+    if (r < L.r_norm) { if (r == L.r_tx) { lo = in.term[0]; up = INF; } else { lo = in.term[1]; up = in.term[2]; } return; }
+    if (r < L.r_dist) { lo = -INF; up = 1.0; return; }
+    if (r < L.r_lam) { lo = in.dmin; up = INF; return; }
+    lo = 0.0; up = INF;
+}
+
+// rotation-equality residuals (hard rows) for the pair pr
+__device__ __forceinline__ void rot_value(const Lay& L, const double* xv, const double* ct, const double* st,
+                                          const double* cc, int pr, double& e1, double& e2) {
+    const int k = pr / L.nO, i = pr - k * L.nO;
+    const double* mu = xv + L.imu(k) + 4 * i;
+    const double c0 = cc[2 * pr], c1 = cc[2 * pr + 1];
+    e1 = mu[0] - mu[2] + ct[k] * c0 + st[k] * c1;
+    e2 = mu[1] - mu[3] - st[k] * c0 + ct[k] * c1;
+}
+
+// scaled objective sf*f (all lanes return the same value); optionally its gradient into S.gf
+template <bool GRAD>
+__device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, const double* xv, double sf, int lane) {
+    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double h = T * in.Ts;
+    double part = 0.0, gT = 0.0;
+    for (int k = lane; k <= L.N; k += 64) {
+        const double* pk = xv + L.ip(k);
+        const double* W = (k < L.N) ? in.Q : in.P;
+        double e[3], We[3];
+        for (int j = 0; j < 3; ++j) e[j] = pk[j] - S.xref[j * (L.N + 1) + k];
+        for (int a = 0; a < 3; ++a) We[a] = W[3 * a] * e[0] + W[3 * a + 1] * e[1] + W[3 * a + 2] * e[2];
+        part += e[0] * We[0] + e[1] * We[1] + e[2] * We[2];
+        if (GRAD) for (int a = 0; a < 3; ++a) S.gf[L.ip(k) + a] = sf * 2.0 * We[a];
+        if (k < L.N) {
+            const double* u = xv + L.iu(k);
+            const double r0 = in.R1[0] * u[0] + in.R1[1] * u[1], r1 = in.R1[2] * u[0] + in.R1[3] * u[1];
+            part += u[0] * r0 + u[1] * r1;
+            double g0 = 2.0 * r0, g1 = 2.0 * r1;
+            if (k + 1 < L.N) {          // (u_{k+1}-u_k)' R2 (.) / h^2
+                const double* un = xv + L.iu(k + 1);
+                const double q0 = un[0] - u[0], q1 = un[1] - u[1];
+                const double s0 = in.R2[0] * q0 + in.R2[1] * q1, s1 = in.R2[2] * q0 + in.R2[3] * q1;
+                const double qq = q0 * s0 + q1 * s1;
+                part += qq / (h * h);
+                g0 -= 2.0 * s0 / (h * h);
+                g1 -= 2.0 * s1 / (h * h);
+                gT += -2.0 * qq / (h * h * T);
+            }
+            if (k >= 1) {
+                const double* um = xv + L.iu(k - 1);
+                const double q0 = u[0] - um[0], q1 = u[1] - um[1];
+                g0 += 2.0 * (in.R2[0] * q0 + in.R2[1] * q1) / (h * h);
+                g1 += 2.0 * (in.R2[2] * q0 + in.R2[3] * q1) / (h * h);
+            }
+            if (GRAD) { S.gf[L.iu(k)] = sf * g0; S.gf[L.iu(k) + 1] = sf * g1; }
+        }
+    }
+    double f = wave_sum(part);
+    if (L.free_T) {
+        f += (L.N + 1) * (10.0 * T + T * T);
+        if (GRAD) {
+            gT = wave_sum(gT) + (L.N + 1) * (10.0 + 2.0 * T);
+            if (lane == 0) S.gf[L.iT()] = sf * gT;
+        }
+    }
+    if (GRAD) {
+        for (int k = 0; k <= L.N; ++k) {
+            const int w = L.M + 4 * L.nO;
+            for (int j = lane; j < w; j += 64) S.gf[L.il(k) + j] = 0.0;
+        }
+        SYNC();
+    }
+    return sf * f;
+}
+
+// out = gf + J^T ymul (+ rotation rows with nu): gradient of the Lagrangian w.r.t. x.
+// One target entry per lane (gather form, deterministic).
+__device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const double* ym, double* out, int lane) {
+    const double* xv = S.x;
+    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double h = T * in.Ts;
+    // poses and inputs
+    for (int t = lane; t < (L.N + 1) * 5; t += 64) {
+        const int k = t / 5, j = t - 5 * k;
+        if (j >= 3 && k == L.N) continue;
+        const double cs = S.ct[k], sn = S.st[k];
+        double v;
+        if (j < 3) {
+            v = S.gf[L.ip(k) + j];
+            if (k == 0) v += ym[L.r_init + j];
+            if (k >= 1) v += ym[L.r_dyn + 3 * (k - 1) + j];
+            if (k < L.N) {
+                const double* yd = ym + L.r_dyn + 3 * k;
+                v -= yd[j];
+                if (j == 2) {
+                    const double vel = xv[L.iu(k)];
+                    v -= h * vel * (-sn * yd[0] + cs * yd[1]);
+                }
+            }
+            if (k == L.N && L.variant == 4) v += ym[L.r_term + j];
+            if (j < 2) {
+                v += ym[L.r_xb + 2 * k + j];
+                if (k == L.N && L.variant == 6) v += ym[L.r_tx + j];
+            }
+            for (int i = 0; i < L.nO; ++i) {
+                const int pr = k * L.nO + i;
+                const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
+                const double yd = ym[L.r_dist + pr];
+                if (j == 0) v += yd * c0;
+                else if (j == 1) v += yd * c1;
+                else {
+                    const double dth = -sn * c0 + cs * c1;
+                    v += yd * in.off * dth + S.nu[2 * pr] * dth + S.nu[2 * pr + 1] * (-cs * c0 - sn * c1);
+                }
+            }
+            out[L.ip(k) + j] = v;
+        } else {
+            const int c = j - 3;
+            v = S.gf[L.iu(k) + c];
+            const double* yd = ym + L.r_dyn + 3 * k;
+            v -= (c == 0) ? h * (cs * yd[0] + sn * yd[1]) : h * yd[2];
+            v += ym[L.r_ub + 2 * k + c];
+            v -= ym[L.r_acc + 2 * k + c] / h;
+            if (k + 1 < L.N) v += ym[L.r_acc + 2 * (k + 1) + c] / h;
+            out[L.iu(k) + c] = v;
+        }
+    }
+    // lambda
+    for (int t = lane; t < (L.N + 1) * L.M; t += 64) {
+        const int k = t / L.M, j = t - k * L.M;
+        int i = 0;
+        while (j >= L.offm[i + 1]) ++i;
+        const int pr = k * L.nO + i;
+        const double a0 = S.Aobs[((size_t)k * L.M + j) * 2], a1 = S.Aobs[((size_t)k * L.M + j) * 2 + 1];
+        const double cs = S.ct[k], sn = S.st[k], c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
+        const double* pk = xv + L.ip(k);
+        const double tx = pk[0] + cs * in.off, ty = pk[1] + sn * in.off;
+        double v = S.nu[2 * pr] * (cs * a0 + sn * a1) + S.nu[2 * pr + 1] * (-sn * a0 + cs * a1);
+        v += ym[L.r_norm + pr] * 2.0 * (a0 * c0 + a1 * c1);
+        v += ym[L.r_dist + pr] * (tx * a0 + ty * a1 - S.bobs[(size_t)k * L.M + j]);
+        v += ym[L.r_lam + t];
+        out[L.il(k) + j] = v;
+    }
+    // mu
+    for (int t = lane; t < (L.N + 1) * 4 * L.nO; t += 64) {
+        const int w4 = 4 * L.nO, k = t / w4, q = t - k * w4, i = q >> 2, j = q & 3;
+        const int pr = k * L.nO + i;
+        const double sgn = (j < 2) ? 1.0 : -1.0;
+        double v = sgn * S.nu[2 * pr + (j & 1)];
+        v -= in.gego[j] * ym[L.r_dist + pr];
+        v += ym[L.r_mu + t];
+        out[L.imu(k) + q] = v;
+    }
+    // time scale
+    if (L.free_T) {
+        double part = 0.0;
+        for (int k = lane; k < L.N; k += 64) {
+            const double* u = xv + L.iu(k);
+            const double* yd = ym + L.r_dyn + 3 * k;
+            part -= in.Ts * (u[0] * S.ct[k] * yd[0] + u[0] * S.st[k] * yd[1] + u[1] * yd[2]);
+            for (int c = 0; c < 2; ++c) {
+                const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
+                part -= ym[L.r_acc + 2 * k + c] * (prev - u[c]) / (T * h);
+            }
+        }
+        part = wave_sum(part);
+        if (lane == 0) out[L.iT()] = S.gf[L.iT()] + part + (L.N + 1) * (ym[L.r_T] + ym[L.r_T + 1]);
+    }
+    SYNC();
+}
+
+// J_r dx for the condensed rows (soft rows get their dy from the Riccati sweep)
+__device__ double row_jdx(const Lay& L, const Sh& S, const Inst& in, int r) {
+    const double* xv = S.x;
+    const double* d = S.dx;
+    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double dT = L.free_T ? d[L.iT()] : 0.0;
+    const double h = T * in.Ts;
+    if (r < L.r_xb) return d[L.ip(L.N) + (r - L.r_term)];
+    if (r < L.r_ub) { const int q = r - L.r_xb; return d[L.ip(q >> 1) + (q & 1)]; }
+    if (r < L.r_acc) { const int q = r - L.r_ub; return d[L.iu(q >> 1) + (q & 1)]; }
+    if (r < L.r_T) {
+        const int q = r - L.r_acc, k = q >> 1, c = q & 1;
+        const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
+        const double dprev = (k == 0) ? 0.0 : d[L.iu(k - 1) + c];
+        const double qq = prev - xv[L.iu(k) + c];
+        return (dprev - d[L.iu(k) + c]) / h - qq / (T * h) * dT;
+    }
+    if (r < L.r_tx) return dT;
+    if (r < L.r_norm) return d[L.ip(L.N) + (r - L.r_tx)];
+    if (r < L.r_lam) {
+        const bool isn = r < L.r_dist;
+        const int pr = isn ? r - L.r_norm : r - L.r_dist;
+        const int k = pr / L.nO, i = pr - k * L.nO;
+        const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
+        const double* A = S.Aobs + (size_t)k * L.M * 2;
+        const double* dl = d + L.il(k);
+        double s0 = 0.0, s1 = 0.0, sb = 0.0;
+        for (int j = L.offm[i]; j < L.offm[i + 1]; ++j) {
+            s0 += A[2 * j] * dl[j];
+            s1 += A[2 * j + 1] * dl[j];
+            sb += S.bobs[(size_t)k * L.M + j] * dl[j];
+        }
+        if (isn) return 2.0 * (c0 * s0 + c1 * s1);
+        const double cs = S.ct[k], sn = S.st[k];
+        const double* pk = xv + L.ip(k);
+        const double* dp = d + L.ip(k);
+        const double* dm = d + L.imu(k) + 4 * i;
+        const double tx = pk[0] + cs * in.off, ty = pk[1] + sn * in.off;
+        return -(in.gego[0] * dm[0] + in.gego[1] * dm[1] + in.gego[2] * dm[2] + in.gego[3] * dm[3]) + tx * s0 +
+               ty * s1 - sb + c0 * dp[0] + c1 * dp[1] + in.off * (-sn * c0 + cs * c1) * dp[2];
+    }
+    if (r < L.r_mu) { const int q = r - L.r_lam, k = q / L.M; return d[L.il(k) + (q - k * L.M)]; }
+    { const int q = r - L.r_mu, w4 = 4 * L.nO, k = q / w4; return d[L.imu(k) + (q - k * w4)]; }
+}
+
+// ---------------------------------------------------------------- per-row barrier algebra
+struct RowLin { double Ds, Dp, Dn, rs, rp, rn, gs; bool hasL, hasU, eq; };
+
+__device__ __forceinline__ RowLin row_lin(const Lay& L, const Sh& S, int r, double mu, double rho, double dw) {
+    RowLin q;
+    q.eq = row_iseq(L, r);
+    const double lo = S.Lb[r], up = S.Ub[r];
+    q.hasL = !q.eq && lo > -INFINITY;
+    q.hasU = !q.eq && up < INFINITY;
+    const double s = S.s[r], y = S.y[r];
+    double sig = 0.0, gs = 0.0;
+    if (q.hasL) { const double sl = s - lo; sig += S.zL[r] / sl; gs -= mu / sl; }
+    if (q.hasU) { const double su = up - s; sig += S.zU[r] / su; gs += mu / su; }
+    if (q.hasL && !q.hasU) gs += OBCA_KAPPA_D * mu;
+    if (q.hasU && !q.hasL) gs -= OBCA_KAPPA_D * mu;
+    q.gs = gs;
+    q.Ds = sig + dw;
+    q.Dp = S.zp[r] / S.p[r] + dw;
+    q.Dn = S.zn[r] / S.n[r] + dw;
+    q.rs = q.eq ? 0.0 : (-y + gs);
+    q.rp = rho - y - mu / S.p[r];
+    q.rn = rho + y - mu / S.n[r];
+    return q;
+}
+
+// ---------------------------------------------------------------- optimality error  (IPOPT eq. (5)/(6))
+struct Err { double E, dual, prim, comp; };
+
+__device__ Err ipm_errors(const Lay& L, const Sh& S, double mu, double rho, double rxmax, double crotmax,
+                          double nusum, int lane) {
+    double dual = 0.0, prim = 0.0, comp = 0.0, ysum = 0.0, zsum = 0.0, nz = 0.0, nrow = 0.0;
+    for (int r = lane; r < L.R; r += 64) {
+        const double w = row_w(L, r);
+        const bool eq = row_iseq(L, r);
+        const double lo = S.Lb[r], up = S.Ub[r];
+        const bool hasL = !eq && lo > -INFINITY, hasU = !eq && up < INFINITY;
+        const double s = S.s[r], y = S.y[r], p = S.p[r], n = S.n[r];
+        const double zL = hasL ? S.zL[r] : 0.0, zU = hasU ? S.zU[r] : 0.0, zp = S.zp[r], zn = S.zn[r];
+        if (!eq) dual = dmaxabs(dual, -y - zL + zU);
+        dual = dmaxabs(dual, rho - y - zp);
+        dual = dmaxabs(dual, rho + y - zn);
+        prim = dmaxabs(prim, S.g[r] - (eq ? 0.0 : s) - p + n);
+        comp = dmaxabs(comp, p * zp - mu);
+        comp = dmaxabs(comp, n * zn - mu);
+        if (hasL) comp = dmaxabs(comp, (s - lo) * zL - mu);
+        if (hasU) comp = dmaxabs(comp, (up - s) * zU - mu);
+        ysum += w * fabs(y);
+        zsum += w * (zL + zU + zp + zn);
+        nz += w * ((hasL ? 1.0 : 0.0) + (hasU ? 1.0 : 0.0) + 2.0);
+        nrow += w;
+    }
+    dual = fmax(wave_max(dual), rxmax);
+    prim = fmax(wave_max(prim), crotmax);
+    comp = wave_max(comp);
+    ysum = wave_sum(ysum) + nusum;
+    zsum = wave_sum(zsum);
+    nz = wave_sum(nz);
+    nrow = wave_sum(nrow) + 2.0 * L.npair;
+    const double sd = fmax(OBCA_S_MAX, (ysum + zsum) / (nrow + nz)) / OBCA_S_MAX;
+    const double sc = fmax(OBCA_S_MAX, zsum / nz) / OBCA_S_MAX;
+    Err e;
+    e.dual = dual; e.prim = prim; e.comp = comp;
+    e.E = fmax(fmax(dual / sd, prim), comp / sc);
+    return e;
+}
+
+// ---------------------------------------------------------------- stage-cost assembly (one lane per stage)
+// Lall[k] is the 8x8 symmetric stage matrix over (dp(0:3), du_prev(3:5), dT(5), du(6:8)); lall[k] its gradient.
+__device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, double sf, double dw, int lane) {
+    const double* xv = S.x;
+    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double h = T * in.Ts, ih2 = 1.0 / (h * h);
+    double HTT = 0.0;
+    for (int k = lane; k <= L.N; k += 64) {
+        double* H = S.Lall + 64 * k;
+        double* lv = S.lall + 8 * k;
+        for (int a = 0; a < 64; ++a) H[a] = 0.0;
+        const double cs = S.ct[k], sn = S.st[k];
+        const double* W = (k < L.N) ? in.Q : in.P;
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) H[8 * a + b] = sf * 2.0 * W[3 * a + b];
+            H[8 * a + a] += dw;
+            lv[a] = S.bx[L.ip(k) + a];
+        }
+        lv[3] = lv[4] = lv[5] = 0.0;
+        for (int j = 0; j < 2; ++j) {                               // position box rows
+            H[8 * j + j] += S.Einv[L.r_xb + 2 * k + j];
+        }
+        if (k == L.N && L.variant == 4) for (int j = 0; j < 3; ++j) H[8 * j + j] += S.Einv[L.r_term + j];
+        if (k == L.N && L.variant == 6) for (int j = 0; j < 2; ++j) H[8 * j + j] += S.Einv[L.r_tx + j];
+        double hth = 0.0;                                           // theta-theta Lagrangian curvature
+        for (int i = 0; i < L.nO; ++i) {
+            const int pr = k * L.nO + i;
+            const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
+            const double yd = S.y[L.r_dist + pr], Ei = S.Einv[L.r_dist + pr];
+            const double gp[3] = {c0, c1, in.off * (-sn * c0 + cs * c1)};
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) H[8 * a + b] += Ei * gp[a] * gp[b];
+            hth += yd * in.off * (-cs * c0 - sn * c1);
+            hth += S.nu[2 * pr] * (-cs * c0 - sn * c1) + S.nu[2 * pr + 1] * (sn * c0 - cs * c1);
+        }
+        if (k < L.N) {
+            const double* u = xv + L.iu(k);
+            const double* yd = S.y + L.r_dyn + 3 * k;
+            hth += h * u[0] * (yd[0] * cs + yd[1] * sn);
+            const double hpu = h * (yd[0] * sn - yd[1] * cs);       // theta - v
+            H[8 * 2 + 6] += hpu;
+            H[8 * 6 + 2] += hpu;
+            for (int a = 0; a < 2; ++a) {
+                for (int b = 0; b < 2; ++b) H[8 * (6 + a) + 6 + b] = sf * 2.0 * in.R1[2 * a + b];
+                H[8 * (6 + a) + 6 + a] += dw + S.Einv[L.r_ub + 2 * k + a];
+                lv[6 + a] = S.bx[L.iu(k) + a];
+            }
+            // acceleration cost couples u_k with u_{k-1} (stage k) and u_{k+1} (stage k+1)
+            const int ncost = (k + 1 < L.N ? 1 : 0) + (k >= 1 ? 1 : 0);
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) H[8 * (6 + a) + 6 + b] += sf * 2.0 * in.R2[2 * a + b] * ih2 * ncost;
+            if (k >= 1)
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {
+                        const double v = -sf * 2.0 * in.R2[2 * a + b] * ih2;
+                        H[8 * (3 + a) + 6 + b] += v;
+                        H[8 * (6 + b) + 3 + a] += v;
+                    }
+            // acceleration rows k (u_{k-1}, u_k) and k+1 (u_k, u_{k+1})
+            for (int c = 0; c < 2; ++c) {
+                const double Ek = S.Einv[L.r_acc + 2 * k + c];
+                H[8 * (6 + c) + 6 + c] += Ek * ih2;
+                if (k >= 1) {
+                    H[8 * (3 + c) + 6 + c] -= Ek * ih2;
+                    H[8 * (6 + c) + 3 + c] -= Ek * ih2;
+                }
+                if (k + 1 < L.N) H[8 * (6 + c) + 6 + c] += S.Einv[L.r_acc + 2 * (k + 1) + c] * ih2;
+            }
+            if (L.free_T) {
+                // (theta,T), (u,T) and (T,T) entries
+                double hpT = -in.Ts * u[0] * (-yd[0] * sn + yd[1] * cs);
+                double huT[2] = {-in.Ts * (yd[0] * cs + yd[1] * sn), -in.Ts * yd[2]};
+                for (int c = 0; c < 2; ++c) {
+                    const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
+                    const double q = prev - u[c];
+                    const double ya = S.y[L.r_acc + 2 * k + c], Ek = S.Einv[L.r_acc + 2 * k + c];
+                    huT[c] += ya / (T * h) + Ek * q / (T * h * h);
+                    HTT += ya * 2.0 * q / (T * T * h) + Ek * q * q / (T * T * h * h);
+                    if (k + 1 < L.N) {
+                        const double qn = u[c] - xv[L.iu(k + 1) + c];
+                        const double yn = S.y[L.r_acc + 2 * (k + 1) + c], En = S.Einv[L.r_acc + 2 * (k + 1) + c];
+                        huT[c] += -yn / (T * h) - En * qn / (T * h * h);
+                    }
+                }
+                // acceleration cost cross terms
+                double qa[2] = {0, 0}, qb[2] = {0, 0};
+                if (k + 1 < L.N) { qa[0] = xv[L.iu(k + 1)] - u[0]; qa[1] = xv[L.iu(k + 1) + 1] - u[1]; }
+                if (k >= 1) { qb[0] = u[0] - xv[L.iu(k - 1)]; qb[1] = u[1] - xv[L.iu(k - 1) + 1]; }
+                for (int a = 0; a < 2; ++a) {
+                    const double Ra = in.R2[2 * a] * qa[0] + in.R2[2 * a + 1] * qa[1];
+                    const double Rb = in.R2[2 * a] * qb[0] + in.R2[2 * a + 1] * qb[1];
+                    huT[a] += sf * 4.0 * ih2 / T * (Ra - Rb);
+                }
+                if (k + 1 < L.N) {
+                    const double qq = qa[0] * (in.R2[0] * qa[0] + in.R2[1] * qa[1]) + qa[1] * (in.R2[2] * qa[0] + in.R2[3] * qa[1]);
+                    HTT += sf * 6.0 * qq * ih2 / (T * T);
+                }
+                H[8 * 2 + 5] += hpT; H[8 * 5 + 2] += hpT;
+                for (int c = 0; c < 2; ++c) { H[8 * (6 + c) + 5] += huT[c]; H[8 * 5 + 6 + c] += huT[c]; }
+            }
+        } else {
+            lv[6] = lv[7] = 0.0;
+            H[8 * 6 + 6] = 1.0; H[8 * 7 + 7] = 1.0;     // no input at the last stage
+        }
+        H[8 * 2 + 2] += hth;
+    }
+    if (L.free_T) {
+        HTT = wave_sum(HTT);
+        if (lane == 0) {
+            const double w = (double)(L.N + 1);
+            HTT += sf * 2.0 * w + dw * w + w * (S.Einv[L.r_T] + S.Einv[L.r_T + 1]);
+            S.Lall[8 * 5 + 5] += HTT;
+            S.lall[5] = S.bx[L.iT()];
+        }
+    } else if (lane == 0) {
+        S.Lall[8 * 5 + 5] = 1.0;                       // dT pinned to zero in the fixed-time variants
+    }
+    SYNC();
+}
+
+// ---------------------------------------------------------------- level 1: local blocks, one lane per pair
+// Writes Y[pr] = Kloc^-1 [G | rloc] (MW x 4) and Sloc[pr] = (G^T Y_G (3x3), G^T Y_r (3)). Returns 1 on a
+// wrong-sign pivot.
+__device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw, int lane) {
+    int bad = 0;
+    for (int pr = lane; pr < L.npair; pr += 64) {
+        const int k = pr / L.nO, i = pr - k * L.nO;
+        const int o0 = L.offm[i], m = L.offm[i + 1] - o0;
+        const double cs = S.ct[k], sn = S.st[k];
+        const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
+        const double* pk = S.x + L.ip(k);
+        const double tx = pk[0] + cs * in.off, ty = pk[1] + sn * in.off;
+        const double yn = S.y[L.r_norm + pr], En = S.Einv[L.r_norm + pr];
+        const double yd = S.y[L.r_dist + pr], Ed = S.Einv[L.r_dist + pr];
+        const double nu1 = S.nu[2 * pr], nu2 = S.nu[2 * pr + 1];
+        double a0[OBCA_MAX_EDGES], a1[OBCA_MAX_EDGES], gn[NW], gd[NW];
+        double K[MW][MW], G[MW][3], rl[MW];
+#pragma unroll
+        for (int a = 0; a < MW; ++a) {
+#pragma unroll
+            for (int b = 0; b < MW; ++b) K[a][b] = 0.0;
+            G[a][0] = G[a][1] = G[a][2] = 0.0;
+            rl[a] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
+            const bool on = j < m;
+            a0[j] = on ? S.Aobs[((size_t)k * L.M + o0 + j) * 2] : 0.0;
+            a1[j] = on ? S.Aobs[((size_t)k * L.M + o0 + j) * 2 + 1] : 0.0;
+            const double bj = on ? S.bobs[(size_t)k * L.M + o0 + j] : 0.0;
+            gn[j] = 2.0 * (a0[j] * c0 + a1[j] * c1);
+            gd[j] = on ? (tx * a0[j] + ty * a1[j] - bj) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gn[OBCA_MAX_EDGES + j] = 0.0; gd[OBCA_MAX_EDGES + j] = -in.gego[j]; }
+        // primal block
+#pragma unroll
+        for (int a = 0; a < NW; ++a)
+#pragma unroll
+            for (int b = 0; b < NW; ++b) {
+                double v = En * gn[a] * gn[b] + Ed * gd[a] * gd[b];
+                if (a < OBCA_MAX_EDGES && b < OBCA_MAX_EDGES) v += yn * 2.0 * (a0[a] * a0[b] + a1[a] * a1[b]);
+                K[a][b] = v;
+            }
+#pragma unroll
+        for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
+            const bool on = j < m;
+            K[j][j] += on ? (dw + S.Einv[L.r_lam + k * L.M + o0 + j]) : 1.0;   // padded slots: identity
+            rl[j] = on ? -S.bx[L.il(k) + o0 + j] : 0.0;
+            // coupling to the pose: rows (x, y, theta)
+            G[j][0] = Ed * gd[j] * c0 + yd * a0[j];
+            G[j][1] = Ed * gd[j] * c1 + yd * a1[j];
+            G[j][2] = Ed * gd[j] * in.off * (-sn * c0 + cs * c1) + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
+                      nu1 * (-sn * a0[j] + cs * a1[j]) + nu2 * (-cs * a0[j] - sn * a1[j]);
+            // rotation rows
+            K[NW][j] = K[j][NW] = cs * a0[j] + sn * a1[j];
+            K[NW + 1][j] = K[j][NW + 1] = -sn * a0[j] + cs * a1[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = OBCA_MAX_EDGES + j;
+            K[a][a] += dw + S.Einv[L.r_mu + k * 4 * L.nO + 4 * i + j];
+            rl[a] = -S.bx[L.imu(k) + 4 * i + j];
+            G[a][0] = Ed * gd[a] * c0;
+            G[a][1] = Ed * gd[a] * c1;
+            G[a][2] = Ed * gd[a] * in.off * (-sn * c0 + cs * c1);
+        }
+        K[NW][OBCA_MAX_EDGES + 0] = K[OBCA_MAX_EDGES + 0][NW] = 1.0;
+        K[NW][OBCA_MAX_EDGES + 2] = K[OBCA_MAX_EDGES + 2][NW] = -1.0;
+        K[NW + 1][OBCA_MAX_EDGES + 1] = K[OBCA_MAX_EDGES + 1][NW + 1] = 1.0;
+        K[NW + 1][OBCA_MAX_EDGES + 3] = K[OBCA_MAX_EDGES + 3][NW + 1] = -1.0;
+        G[NW][2] = -sn * c0 + cs * c1;
+        G[NW + 1][2] = -cs * c0 - sn * c1;
+        rl[NW] = -S.crot[2 * pr];
+        rl[NW + 1] = -S.crot[2 * pr + 1];
+        // LDL^T without pivoting (quasi-definite when the primal block is positive definite)
+        double Yv[MW][4];
+#pragma unroll
+        for (int a = 0; a < MW; ++a) { Yv[a][0] = G[a][0]; Yv[a][1] = G[a][1]; Yv[a][2] = G[a][2]; Yv[a][3] = rl[a]; }
+        double dinv[MW];
+#pragma unroll
+        for (int j = 0; j < MW; ++j) {
+            const double d = K[j][j];
+            if (j < NW ? !(d > 0.0) : !(d < 0.0)) bad = 1;
+            dinv[j] = 1.0 / d;
+#pragma unroll
+            for (int a = j + 1; a < MW; ++a) {          // trailing update with the unscaled column
+                const double la = K[a][j] * dinv[j];
+#pragma unroll
+                for (int b = j + 1; b <= a; ++b) K[a][b] -= la * K[b][j];
+            }
+#pragma unroll
+            for (int a = j + 1; a < MW; ++a) {
+                K[a][j] *= dinv[j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Yv[a][c] -= K[a][j] * Yv[j][c];       // forward substitution
+            }
+        }
+#pragma unroll
+        for (int j = MW - 1; j >= 0; --j) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double v = Yv[j][c] * dinv[j];
+#pragma unroll
+                for (int a = j + 1; a < MW; ++a) v -= K[a][j] * Yv[a][c];
+                Yv[j][c] = v;
+            }
+        }
+        double* Yo = S.Y + (size_t)pr * (MW * 4);
+#pragma unroll
+        for (int a = 0; a < MW; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Yo[4 * a + c] = Yv[a][c];
+        double* So = S.Sloc + (size_t)pr * 12;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double v = 0.0;
+#pragma unroll
+                for (int e = 0; e < MW; ++e) v += G[e][a] * Yv[e][c];
+                So[4 * a + c] = v;
+            }
+    }
+    SYNC();
+    // fold the Schur complements into the stage blocks
+    for (int k = lane; k <= L.N; k += 64) {
+        double* H = S.Lall + 64 * k;
+        double* lv = S.lall + 8 * k;
+        for (int i = 0; i < L.nO; ++i) {
+            const double* So = S.Sloc + (size_t)(k * L.nO + i) * 12;
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) H[8 * a + b] -= 0.5 * (So[4 * a + b] + So[4 * b + a]);
+                lv[a] += So[4 * a + 3];
+            }
+        }
+    }
+    SYNC();
+    return wave_or(bad);
+}
+
+// (I + Ppp E)^-1 by LU without pivoting; pivots equal those of I + E^1/2 Ppp E^1/2
+__device__ __forceinline__ int inv3_ipe(const double* P, int ld, const double* E, double Mi[9]) {
+    double A[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { A[3 * a + b] = P[ld * a + b] * E[b] + (a == b ? 1.0 : 0.0); Mi[3 * a + b] = (a == b ? 1.0 : 0.0); }
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (!(A[3 * j + j] > 0.0)) bad = 1;
+#pragma unroll
+        for (int i = j + 1; i < 3; ++i) {
+            const double f = A[3 * i + j] / A[3 * j + j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { A[3 * i + c] -= f * A[3 * j + c]; Mi[3 * i + c] -= f * Mi[3 * j + c]; }
+        }
+    }
+#pragma unroll
+    for (int j = 2; j >= 0; --j) {
+        const double inv = 1.0 / A[3 * j + j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Mi[3 * j + c] *= inv;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < j) {
+                const double f = A[3 * i + j];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Mi[3 * i + c] -= f * Mi[3 * j + c];
+            }
+    }
+    return bad;
+}
+
+// soft-min of V(p', o) = 1/2 [p';o]'P[p';o] + q'[p';o] against 1/2 (p'-phat)' E^-1 (p'-phat); writes X, qt
+__device__ int soft_min(const Sh& S, const double* P, const double* q, const double* E, double* MiOut, int lane) {
+    double Mi[9];
+    const int bad = inv3_ipe(P, 6, E, Mi);
+    if (lane < 9) MiOut[lane] = Mi[lane];
+    if (lane < 36) {
+        const int a = lane / 6, b = lane - 6 * a;
+        double v;
+        if (a < 3) {                               // M [Ppp Ppo]
+            v = Mi[3 * a] * P[b] + Mi[3 * a + 1] * P[6 + b] + Mi[3 * a + 2] * P[12 + b];
+        } else if (b < 3) {                        // symmetric copy of (M Ppo)'
+            v = Mi[3 * b] * P[a] + Mi[3 * b + 1] * P[6 + a] + Mi[3 * b + 2] * P[12 + a];
+        } else {                                   // Poo - Pop E M Ppo
+            v = P[6 * a + b];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double emp = E[c] * (Mi[3 * c] * P[b] + Mi[3 * c + 1] * P[6 + b] + Mi[3 * c + 2] * P[12 + b]);
+                v -= P[6 * a + c] * emp;
+            }
+        }
+        S.X[lane] = v;
+    } else if (lane < 42) {
+        const int a = lane - 36;
+        double v;
+        if (a < 3) v = Mi[3 * a] * q[0] + Mi[3 * a + 1] * q[1] + Mi[3 * a + 2] * q[2];
+        else {
+            v = q[a];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v -= P[6 * a + c] * E[c] * (Mi[3 * c] * q[0] + Mi[3 * c + 1] * q[1] + Mi[3 * c + 2] * q[2]);
+        }
+        S.qt[a] = v;
+    }
+    SYNC();
+    double vsym = 0.0;
+    if (lane < 9) {                                // symmetrise the pp block
+        const int a = lane / 3, b = lane - 3 * a;
+        vsym = 0.5 * (S.X[6 * a + b] + S.X[6 * b + a]);
+    }
+    SYNC();
+    if (lane < 9) {
+        const int a = lane / 3, b = lane - 3 * a;
+        S.X[6 * a + b] = vsym;
+    }
+    SYNC();
+    return bad;
+}
+
+// ---------------------------------------------------------------- level 2: Riccati sweep + forward pass
+// Returns 1 on a wrong-sign pivot.  On success dx (poses, inputs, T) and dy of the soft rows are written.
+__device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
+    const double* xv = S.x;
+    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double h = T * in.Ts;
+    int bad = 0;
+    // terminal value function
+    double* PN = S.Pk + 36 * L.N;
+    double* qN = S.qk + 6 * L.N;
+    if (lane < 36) {
+        const int a = lane / 6, b = lane - 6 * a;
+        PN[lane] = (a < 3 && b < 3) ? S.Lall[64 * L.N + 8 * a + b] : 0.0;
+    } else if (lane < 42) {
+        const int a = lane - 36;
+        qN[a] = (a < 3) ? S.lall[8 * L.N + a] : 0.0;
+    }
+    SYNC();
+    for (int k = L.N - 1; k >= 0; --k) {
+        const double* P1 = S.Pk + 36 * (k + 1);
+        const double* q1 = S.qk + 6 * (k + 1);
+        double E[3], gh[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { E[j] = 1.0 / S.Einv[L.r_dyn + 3 * k + j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
+        bad |= soft_min(S, P1, q1, E, S.Mik + 9 * k, lane);
+        // [F G] (6 x 8) and f
+        if (lane < 48) {
+            const int a = lane / 8, b = lane - 8 * a;
+            const double cs = S.ct[k], sn = S.st[k];
+            const double* u = xv + L.iu(k);
+            double v = 0.0;
+            if (a < 3) {
+                if (b < 3) v = (a == b) ? 1.0 : 0.0;
+                if (b == 2) { if (a == 0) v = -h * u[0] * sn; else if (a == 1) v = h * u[0] * cs; }
+                if (b == 5 && L.free_T) v = in.Ts * ((a == 0) ? u[0] * cs : (a == 1) ? u[0] * sn : u[1]);
+                if (b == 6) v = (a == 0) ? h * cs : (a == 1) ? h * sn : 0.0;
+                if (b == 7) v = (a == 2) ? h : 0.0;
+            } else if (a < 5) {
+                v = (b == 6 + (a - 3)) ? 1.0 : 0.0;
+            } else {
+                v = (b == 5) ? 1.0 : 0.0;
+            }
+            S.FG[lane] = v;
+        } else if (lane < 54) {
+            const int a = lane - 48;
+            S.fv[a] = (a < 3) ? -gh[a] : 0.0;
+        }
+        SYNC();
+        // Z = X [F G],  zv = X f + qt
+        if (lane < 48) {
+            const int a = lane / 8, b = lane - 8 * a;
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v += S.X[6 * a + c] * S.FG[8 * c + b];
+            S.Z[lane] = v;
+        } else if (lane < 54) {
+            const int a = lane - 48;
+            double v = S.qt[a];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v += S.X[6 * a + c] * S.fv[c];
+            S.zv[a] = v;
+        }
+        SYNC();
+        // Mall = Lall + [F G]' Z,  mall = lall + [F G]' zv
+        {
+            const int a = lane >> 3, b = lane & 7;
+            double v = S.Lall[64 * k + lane];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v += S.FG[8 * c + a] * S.Z[8 * c + b];
+            S.Mall[lane] = v;
+            if (lane < 8) {
+                double w = S.lall[8 * k + lane];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) w += S.FG[8 * c + lane] * S.zv[c];
+                S.mall[lane] = w;
+            }
+        }
+        SYNC();
+        // input block: 2x2 Cholesky-type pivots must be positive
+        const double m00 = S.Mall[8 * 6 + 6], m01 = 0.5 * (S.Mall[8 * 6 + 7] + S.Mall[8 * 7 + 6]), m11 = S.Mall[8 * 7 + 7];
+        const double d1 = m11 - m01 * m01 / m00;
+        if (!(m00 > 0.0) || !(d1 > 0.0)) bad = 1;
+        const double idet = 1.0 / (m00 * d1);
+        const double i00 = m11 * idet, i01 = -m01 * idet, i11 = m00 * idet;
+        if (lane < 12) {                                   // K = -Muu^-1 Mxu'
+            const int uu = lane / 6, a = lane - 6 * uu;
+            const double x0 = 0.5 * (S.Mall[8 * a + 6] + S.Mall[8 * 6 + a]), x1 = 0.5 * (S.Mall[8 * a + 7] + S.Mall[8 * 7 + a]);
+            S.Kk[12 * k + lane] = -((uu == 0) ? (i00 * x0 + i01 * x1) : (i01 * x0 + i11 * x1));
+        } else if (lane < 14) {
+            const int uu = lane - 12;
+            S.kapk[2 * k + uu] = -((uu == 0) ? (i00 * S.mall[6] + i01 * S.mall[7]) : (i01 * S.mall[6] + i11 * S.mall[7]));
+        }
+        SYNC();
+        if (lane < 36) {                                   // P_k = Mxx + Mxu K (symmetrised)
+            const int a = lane / 6, b = lane - 6 * a;
+            const double xa0 = 0.5 * (S.Mall[8 * a + 6] + S.Mall[8 * 6 + a]), xa1 = 0.5 * (S.Mall[8 * a + 7] + S.Mall[8 * 7 + a]);
+            const double xb0 = 0.5 * (S.Mall[8 * b + 6] + S.Mall[8 * 6 + b]), xb1 = 0.5 * (S.Mall[8 * b + 7] + S.Mall[8 * 7 + b]);
+            const double v1 = S.Mall[8 * a + b] + xa0 * S.Kk[12 * k + b] + xa1 * S.Kk[12 * k + 6 + b];
+            const double v2 = S.Mall[8 * b + a] + xb0 * S.Kk[12 * k + a] + xb1 * S.Kk[12 * k + 6 + a];
+            S.Pk[36 * k + lane] = 0.5 * (v1 + v2);
+        } else if (lane < 42) {
+            const int a = lane - 36;
+            const double xa0 = 0.5 * (S.Mall[8 * a + 6] + S.Mall[8 * 6 + a]), xa1 = 0.5 * (S.Mall[8 * a + 7] + S.Mall[8 * 7 + a]);
+            S.qk[6 * k + a] = S.mall[a] + xa0 * S.kapk[2 * k] + xa1 * S.kapk[2 * k + 1];
+        }
+        SYNC();
+    }
+    // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
+    double E0[3], g0[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { E0[j] = 1.0 / S.Einv[L.r_init + j]; g0[j] = S.gh[L.r_init + j]; }
+    bad |= soft_min(S, S.Pk, S.qk, E0, S.Mik + 9 * L.N, lane);
+    if (L.free_T && !(S.X[35] > 0.0)) bad = 1;
+    bad = wave_or(bad);
+    if (bad) return 1;
+    // ---- forward pass: every lane carries the (tiny) state redundantly, lane 0 stores
+    double dT = 0.0;
+    if (L.free_T) dT = -(S.qt[5] - (S.X[30] * g0[0] + S.X[31] * g0[1] + S.X[32] * g0[2])) / S.X[35];
+    double dp[3], up[2] = {0.0, 0.0};
+    {
+        const double* P0 = S.Pk;
+        const double* q0 = S.qk;
+        const double* Mi = S.Mik + 9 * L.N;
+        double t[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t[a] = -g0[a] - E0[a] * (P0[6 * a + 5] * dT + q0[a]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dp[a] = Mi[a] * t[0] + Mi[3 + a] * t[1] + Mi[6 + a] * t[2];   // M' t
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (lane == 0) S.dy[L.r_init + a] = -(P0[6 * a] * dp[0] + P0[6 * a + 1] * dp[1] + P0[6 * a + 2] * dp[2] + P0[6 * a + 5] * dT + q0[a]);
+    }
+    if (lane == 0) {
+        S.dx[0] = dp[0]; S.dx[1] = dp[1]; S.dx[2] = dp[2];
+        if (L.free_T) S.dx[L.iT()] = dT;
+    }
+    for (int k = 0; k < L.N; ++k) {
+        const double* Kg = S.Kk + 12 * k;
+        const double xi[6] = {dp[0], dp[1], dp[2], up[0], up[1], dT};
+        double u[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            double v = S.kapk[2 * k + c];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v += Kg[6 * c + a] * xi[a];
+            u[c] = v;
+        }
+        const double cs = S.ct[k], sn = S.st[k];
+        const double* uk = xv + L.iu(k);
+        double ph[3];
+        ph[0] = dp[0] - h * uk[0] * sn * dp[2] + h * cs * u[0] - S.gh[L.r_dyn + 3 * k];
+        ph[1] = dp[1] + h * uk[0] * cs * dp[2] + h * sn * u[0] - S.gh[L.r_dyn + 3 * k + 1];
+        ph[2] = dp[2] + h * u[1] - S.gh[L.r_dyn + 3 * k + 2];
+        if (L.free_T) { ph[0] += in.Ts * uk[0] * cs * dT; ph[1] += in.Ts * uk[0] * sn * dT; ph[2] += in.Ts * uk[1] * dT; }
+        const double* P1 = S.Pk + 36 * (k + 1);
+        const double* q1 = S.qk + 6 * (k + 1);
+        const double* Mi = S.Mik + 9 * k;
+        double t[3], dn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double E = 1.0 / S.Einv[L.r_dyn + 3 * k + a];
+            t[a] = ph[a] - E * (P1[6 * a + 3] * u[0] + P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dn[a] = Mi[a] * t[0] + Mi[3 + a] * t[1] + Mi[6 + a] * t[2];
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                S.dy[L.r_dyn + 3 * k + a] = -(P1[6 * a] * dn[0] + P1[6 * a + 1] * dn[1] + P1[6 * a + 2] * dn[2] +
+                                              P1[6 * a + 3] * u[0] + P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]);
+                S.dx[L.ip(k + 1) + a] = dn[a];
+            }
+            S.dx[L.iu(k)] = u[0];
+            S.dx[L.iu(k) + 1] = u[1];
+        }
+        dp[0] = dn[0]; dp[1] = dn[1]; dp[2] = dn[2];
+        up[0] = u[0]; up[1] = u[1];
+    }
+    SYNC();
+    // local recovery: [dw; dnu] = Y_r - Y_G dp_k
+    for (int pr = lane; pr < L.npair; pr += 64) {
+        const int k = pr / L.nO, i = pr - k * L.nO;
+        const int o0 = L.offm[i], m = L.offm[i + 1] - o0;
+        const double* Yo = S.Y + (size_t)pr * (MW * 4);
+        const double* d = S.dx + L.ip(k);
+        for (int a = 0; a < MW; ++a) {
+            const double v = Yo[4 * a + 3] - (Yo[4 * a] * d[0] + Yo[4 * a + 1] * d[1] + Yo[4 * a + 2] * d[2]);
+            if (a < OBCA_MAX_EDGES) { if (a < m) S.dx[L.il(k) + o0 + a] = v; }
+            else if (a < NW) S.dx[L.imu(k) + 4 * i + (a - OBCA_MAX_EDGES)] = v;
+            else S.dnu[2 * pr + (a - NW)] = v;
+        }
+    }
+    SYNC();
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================== the kernel
+extern "C" __global__ void __launch_bounds__(64)
+obca_ipm_kernel(ObcaLaunch A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int inst = blockIdx.x;
+    if (inst >= A.B) return;
+
+    // ---- layout ------------------------------------------------------------------------------------
+    Lay L;
+    L.N = A.N; L.nO = A.nO; L.M = A.M;
+    L.variant = A.variant[inst];
+    L.free_T = (L.variant == 4) ? 1 : 0;
+    L.NS = 5 + L.M + 4 * L.nO;
+    L.n = (L.N + 1) * (3 + L.M + 4 * L.nO) + 2 * L.N + L.free_T;
+    L.npair = (L.N + 1) * L.nO;
+    for (int i = 0; i <= OBCA_MAX_OBST; ++i) L.offm[i] = A.offm[i];
+    L.r_init = 0; L.r_dyn = 3; L.r_term = 3 + 3 * L.N;
+    L.r_xb = L.r_term + (L.variant == 4 ? 3 : 0);
+    L.r_ub = L.r_xb + 2 * (L.N + 1);
+    L.r_acc = L.r_ub + 2 * L.N;
+    L.r_T = L.r_acc + 2 * L.N;
+    L.r_tx = L.r_T + (L.free_T ? 2 : 0);
+    L.r_norm = L.r_tx + (L.variant == 6 ? 2 : 0);
+    L.r_dist = L.r_norm + L.npair;
+    L.r_lam = L.r_dist + L.npair;
+    L.r_mu = L.r_lam + (L.N + 1) * L.M;
+    L.R = L.r_mu + (L.N + 1) * 4 * L.nO;
+
+    // ---- LDS carve (sizes are the handle-wide maxima computed on the host the same way) -----------------
+    Sh S;
+    {
+        double* p = smem;
+        auto take = [&](int cnt) { double* q = p; p += (cnt + 1) & ~1; return q; };
+        const int nmax = A.n_max, Rmax = A.R_max, np = L.npair, N1 = L.N + 1;
+        S.x = take(nmax); S.xt = take(nmax); S.dx = take(nmax); S.gf = take(nmax); S.rx = take(nmax); S.bx = take(nmax);
+        S.s = take(Rmax); S.p = take(Rmax); S.n = take(Rmax); S.y = take(Rmax); S.zL = take(Rmax); S.zU = take(Rmax);
+        S.zp = take(Rmax); S.zn = take(Rmax); S.g = take(Rmax); S.Einv = take(Rmax); S.yhat = take(Rmax);
+        S.gh = take(Rmax); S.dy = take(Rmax); S.Lb = take(Rmax); S.Ub = take(Rmax);
+        S.ct = take(N1); S.st = take(N1); S.cc = take(2 * np); S.ctt = take(N1); S.stt = take(N1); S.cct = take(2 * np);
+        S.nu = take(2 * np); S.dnu = take(2 * np); S.crot = take(2 * np);
+        S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
+        S.Lall = take(64 * N1); S.lall = take(8 * N1); S.Sloc = take(12 * np); S.Y = take(MW * 4 * np);
+        S.Pk = take(36 * N1); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
+        S.X = take(36); S.qt = take(6); S.FG = take(48); S.fv = take(6); S.Z = take(48); S.zv = take(6);
+        S.Mall = take(64); S.mall = take(8); S.red = take(8);
+    }
+
+    // ---- instance data ----------------------------------------------------------------------------------
+    Inst in;
+    const ObcaWeightsDev& Wt = L.free_T ? A.prm.free_time : A.prm.fixed_time;
+    for (int j = 0; j < 9; ++j) { in.Q[j] = Wt.Q[j]; in.P[j] = Wt.P[j]; }
+    for (int j = 0; j < 4; ++j) { in.R1[j] = Wt.R1[j]; in.R2[j] = Wt.R2[j]; in.gego[j] = A.prm.gego[j]; }
+    for (int j = 0; j < 2; ++j) { in.xL[j] = A.prm.xL[j]; in.xU[j] = A.prm.xU[j]; in.uL[j] = A.prm.uL[j]; in.uU[j] = A.prm.uU[j]; }
+    in.off = A.prm.off; in.dmin = A.prm.dmin;
+    for (int j = 0; j < 3; ++j) in.x0[j] = A.x0[(size_t)inst * 3 + j];
+    for (int j = 0; j < 2; ++j) in.u0[j] = A.u0[(size_t)inst * 2 + j];
+    in.Ts = A.Ts[inst];
+    for (int j = 0; j < 3; ++j) in.term[j] = (L.variant == 6) ? A.term[(size_t)inst * 3 + j] : 0.0;
+    {
+        const int N1 = L.N + 1;
+        const double* xr = A.xref + (size_t)inst * 3 * N1;
+        for (int t = lane; t < 3 * N1; t += 64) S.xref[t] = xr[t];
+        const double* Ag = A.A + (size_t)inst * N1 * L.M * 2;
+        const double* bg = A.b + (size_t)inst * N1 * L.M;
+        for (int t = lane; t < N1 * L.M * 2; t += 64) {
+            const int k = t / (2 * L.M), q = t - k * 2 * L.M;
+            S.Aobs[t] = Ag[(size_t)(L.variant == 4 ? 0 : k) * L.M * 2 + q];     // q5: mpc4 reads step 0 only
+        }
+        for (int t = lane; t < N1 * L.M; t += 64) {
+            const int k = t / L.M, q = t - k * L.M;
+            S.bobs[t] = bg[(size_t)(L.variant == 4 ? 0 : k) * L.M + q];
+        }
+        SYNC();
+        const double dis = (S.xref[0 * N1 + L.N] - in.x0[0]) + (S.xref[1 * N1 + L.N] - in.x0[1]);   // signed sum (q3)
+        in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
+    }
+
+    const ObcaOptsDev& O = A.prm.opt;
+    const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
+    const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
+    const double acc_objchg = L.free_T ? 1e20 : 1e-6;
+
+    // ---- start point: zeros, Topt = 1 (obca.py:856) -------------------------------------------------------
+    for (int t = lane; t < L.n; t += 64) S.x[t] = 0.0;
+    for (int t = lane; t < 2 * L.npair; t += 64) S.nu[t] = 0.0;
+    SYNC();
+    if (L.free_T && lane == 0) S.x[L.iT()] = 1.0;
+    SYNC();
+    int status = OBCA_STATUS_MAXITER;
+    int it = 0, nfact = 0;
+    double E0 = INFINITY, sf = 1.0, rho = O.rho;
+    bool bad_bounds = false;
+
+    // objective scaling: IPOPT's gradient rule applied to f + rho*sum(p+n)
+    eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
+    double f = eval_objective<true>(L, S, in, S.x, 1.0, lane);
+    {
+        double gm = 0.0;
+        for (int t = lane; t < L.n; t += 64) gm = dmaxabs(gm, S.gf[t]);
+        gm = fmax(wave_max(gm), O.rho);
+        sf = (gm > OBCA_MAX_GRADIENT) ? OBCA_MAX_GRADIENT / gm : 1.0;
+        rho = O.rho * sf;
+    }
+    SYNC();
+    f = eval_objective<true>(L, S, in, S.x, sf, lane);
+    double mu = OBCA_MU_INIT;
+    // rows: bounds, slacks with bound push, elastic variables on their 1-d central path
+    {
+        int bb = 0;
+        for (int r = lane; r < L.R; r += 64) {
+            double lo, up;
+            row_bounds(L, in, r, lo, up);
+            S.Lb[r] = lo; S.Ub[r] = up;
+            const bool eq = row_iseq(L, r);
+            const double g = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
+            double s = g;
+            const bool hasL = lo > -INFINITY, hasU = up < INFINITY;
+            if (eq) s = 0.0;
+            else if (hasL && hasU) {
+                if (!(lo < up)) bb = 1;
+                const double pL = fmin(OBCA_BOUND_PUSH * fmax(1.0, fabs(lo)), OBCA_BOUND_FRAC * (up - lo));
+                const double pU = fmin(OBCA_BOUND_PUSH * fmax(1.0, fabs(up)), OBCA_BOUND_FRAC * (up - lo));
+                s = fmin(fmax(s, lo + pL), up - pU);
+            } else if (hasL) s = fmax(s, lo + OBCA_BOUND_PUSH * fmax(1.0, fabs(lo)));
+            else if (hasU) s = fmin(s, up - OBCA_BOUND_PUSH * fmax(1.0, fabs(up)));
+            const double rr = g - s;
+            const double a = (mu - rho * rr) / (2.0 * rho);
+            const double en = a + sqrt(a * a + mu * rr / (2.0 * rho));
+            const double ep = rr + en;
+            S.g[r] = g; S.s[r] = s; S.p[r] = ep; S.n[r] = en;
+            S.zp[r] = mu / ep; S.zn[r] = mu / en; S.y[r] = rho - mu / ep;
+            S.zL[r] = (!eq && hasL) ? 1.0 : 0.0;
+            S.zU[r] = (!eq && hasU) ? 1.0 : 0.0;
+        }
+        bad_bounds = wave_or(bb) != 0;
+        for (int pr = lane; pr < L.npair; pr += 64) {
+            double e1, e2;
+            rot_value(L, S.x, S.ct, S.st, S.cc, pr, e1, e2);
+            S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;
+        }
+        SYNC();
+    }
+
+    // filter: one entry per lane
+    bool f_valid = false;
+    double f_th = 0.0, f_phi = 0.0;
+    double theta_max = 0.0, theta_min = 0.0;
+    double delta_w_last = 0.0, tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
+    int acc_count = 0;
+    double fobj_prev = 0.0;
+    bool have_prev = false;
+    double elastic_max = 0.0;
+
+    if (bad_bounds) status = OBCA_STATUS_BAD_BOUNDS;
+    else
+    for (it = 0; it <= max_iter; ++it) {
+        // ---- gradient of the Lagrangian and optimality error ------------------------------------------
+        gather_grad(L, S, in, S.y, S.rx, lane);
+        double rxmax = 0.0, crotmax = 0.0, nusum = 0.0, th = 0.0, pnsum = 0.0;
+        for (int t = lane; t < L.n; t += 64) rxmax = dmaxabs(rxmax, S.rx[t]);
+        for (int t = lane; t < 2 * L.npair; t += 64) { crotmax = dmaxabs(crotmax, S.crot[t]); nusum += fabs(S.nu[t]); th += fabs(S.crot[t]); }
+        double emax = 0.0;
+        for (int r = lane; r < L.R; r += 64) {
+            const double w = row_w(L, r);
+            th += w * fabs(S.g[r] - (row_iseq(L, r) ? 0.0 : S.s[r]) - S.p[r] + S.n[r]);
+            pnsum += w * (S.p[r] + S.n[r]);
+            emax = fmax(emax, S.p[r] + S.n[r]);
+        }
+        rxmax = wave_max(rxmax); crotmax = wave_max(crotmax); nusum = wave_sum(nusum); th = wave_sum(th);
+        pnsum = wave_sum(pnsum); elastic_max = wave_max(emax);
+        const Err e0 = ipm_errors(L, S, 0.0, rho, rxmax, crotmax, nusum, lane);
+        E0 = e0.E;
+        if (it == 0) {
+            theta_max = OBCA_THETA_MAX_FACT * fmax(1.0, th);
+            theta_min = OBCA_THETA_MIN_FACT * fmax(1.0, th);
+        }
+        if (E0 <= O.tol && e0.dual <= 1.0 && e0.prim <= 1e-4 && e0.comp <= 1e-4) { status = OBCA_STATUS_OK; break; }
+        const double fobj = f + rho * pnsum;
+        const double objchg = have_prev ? fabs(fobj - fobj_prev) / fmax(1.0, fabs(fobj)) : INFINITY;
+        if (E0 <= acc_tol && e0.dual <= 1e10 && e0.prim <= 1e-2 && e0.comp <= 1e-2 && objchg <= acc_objchg) {
+            if (++acc_count >= OBCA_ACCEPTABLE_ITER) { status = OBCA_STATUS_ACCEPTABLE; break; }
+        } else acc_count = 0;
+        if (it == max_iter) break;
+        // ---- barrier parameter ---------------------------------------------------------------------------
+        {
+            const double mu_floor = O.tol / (OBCA_KAPPA_EPS + 1.0);
+            while (mu > mu_floor) {
+                const Err em = ipm_errors(L, S, mu, rho, rxmax, crotmax, nusum, lane);
+                if (em.E > OBCA_KAPPA_EPS * mu) break;
+                mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, pow(mu, OBCA_THETA_MU)));
+                tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
+                f_valid = false;
+            }
+        }
+        // ---- Newton step with inertia correction -----------------------------------------------------------
+        double delta_w = 0.0;
+        bool first_try = true;
+        int fail = 0;
+        for (;;) {
+            for (int r = lane; r < L.R; r += 64) {
+                const RowLin q = row_lin(L, S, r, mu, rho, delta_w);
+                const double E = (q.eq ? 0.0 : 1.0 / q.Ds) + 1.0 / q.Dp + 1.0 / q.Dn;
+                const double rg = S.g[r] - (q.eq ? 0.0 : S.s[r]) - S.p[r] + S.n[r];
+                const double gh = rg + (q.eq ? 0.0 : q.rs / q.Ds) + q.rp / q.Dp - q.rn / q.Dn;
+                S.Einv[r] = 1.0 / E;
+                S.gh[r] = gh;
+                S.yhat[r] = row_soft(L, r) ? S.y[r] : (S.y[r] + gh / E);
+            }
+            SYNC();
+            gather_grad(L, S, in, S.yhat, S.bx, lane);
+            assemble_stages(L, S, in, sf, delta_w, lane);
+            int bad = local_blocks(L, S, in, delta_w, lane);
+            if (!bad) bad = riccati(L, S, in, lane);
+            ++nfact;
+            if (!bad) break;
+            if (first_try) {
+                delta_w = (delta_w_last == 0.0) ? OBCA_DELTA_W_0 : fmax(OBCA_DELTA_W_MIN, OBCA_KAPPA_W_MINUS * delta_w_last);
+                first_try = false;
+            } else {
+                delta_w *= (delta_w_last == 0.0) ? OBCA_KAPPA_W_PLUS_BAR : OBCA_KAPPA_W_PLUS;
+            }
+            if (delta_w > OBCA_DELTA_W_MAX) { fail = 1; break; }
+        }
+        if (fail) { status = OBCA_STATUS_NUMERIC; break; }
+        if (delta_w > 0.0) delta_w_last = delta_w;
+        // ---- row steps, step lengths, directional derivative -----------------------------------------------
+        double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0;
+        for (int r = lane; r < L.R; r += 64) {
+            const RowLin q = row_lin(L, S, r, mu, rho, delta_w);
+            double dy;
+            if (row_soft(L, r)) dy = S.dy[r];
+            else { dy = (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r]; S.dy[r] = dy; }
+            const double w = row_w(L, r);
+            const double ds = q.eq ? 0.0 : (dy - q.rs) / q.Ds;
+            const double dp = (dy - q.rp) / q.Dp;
+            const double dn = (-dy - q.rn) / q.Dn;
+            const double s = S.s[r], p = S.p[r], n = S.n[r];
+            const double lo = S.Lb[r], up = S.Ub[r];
+            if (q.hasL) {
+                const double sl = s - lo, zL = S.zL[r];
+                if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
+                const double dz = (mu - zL * ds) / sl - zL;
+                if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
+                phi -= w * mu * log(sl);
+                if (!q.hasU) phi += w * OBCA_KAPPA_D * mu * sl;
+            }
+            if (q.hasU) {
+                const double su = up - s, zU = S.zU[r];
+                if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
+                const double dz = (mu + zU * ds) / su - zU;
+                if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
+                phi -= w * mu * log(su);
+                if (!q.hasL) phi += w * OBCA_KAPPA_D * mu * su;
+            }
+            if (dp < 0.0) a_max = fmin(a_max, -tau * p / dp);
+            if (dn < 0.0) a_max = fmin(a_max, -tau * n / dn);
+            const double zp = S.zp[r], zn = S.zn[r];
+            const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
+            if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
+            if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
+            phi += w * (rho * (p + n) - mu * (log(p) + log(n)));
+            dphi += w * (q.gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
+        }
+        for (int t = lane; t < L.n; t += 64) dphi += S.gf[t] * S.dx[t];
+        a_max = wave_min(a_max); a_z = wave_min(a_z); dphi = wave_sum(dphi); phi = wave_sum(phi) + f;
+        double alpha_min;
+        if (dphi < 0.0) {
+            double c = fmin(OBCA_GAMMA_THETA, OBCA_GAMMA_PHI * th / (-dphi));
+            if (th <= theta_min) c = fmin(c, OBCA_DELTA * pow(th, OBCA_S_THETA) / pow(-dphi, OBCA_S_PHI));
+            alpha_min = OBCA_GAMMA_ALPHA * c;
+        } else alpha_min = OBCA_GAMMA_ALPHA * OBCA_GAMMA_THETA;
+        // ---- backtracking filter line search ---------------------------------------------------------------
+        double alpha = a_max, f_t = f;
+        bool accepted = false, aug = false;
+        for (;;) {
+            for (int t = lane; t < L.n; t += 64) S.xt[t] = S.x[t] + alpha * S.dx[t];
+            SYNC();
+            eval_geom(L, S, S.xt, S.ctt, S.stt, S.cct, lane);
+            f_t = eval_objective<false>(L, S, in, S.xt, sf, lane);
+            double th_t = 0.0, phi_t = 0.0;
+            for (int r = lane; r < L.R; r += 64) {
+                const RowLin q = row_lin(L, S, r, mu, rho, delta_w);
+                const double dy = S.dy[r];
+                const double w = row_w(L, r);
+                const double st = q.eq ? 0.0 : S.s[r] + alpha * (dy - q.rs) / q.Ds;
+                const double pt = S.p[r] + alpha * (dy - q.rp) / q.Dp;
+                const double nt = S.n[r] + alpha * (-dy - q.rn) / q.Dn;
+                const double gt = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
+                th_t += w * fabs(gt - st - pt + nt);
+                phi_t += w * (rho * (pt + nt) - mu * (log(pt) + log(nt)));
+                if (q.hasL) { const double sl = st - S.Lb[r]; phi_t -= w * mu * log(sl); if (!q.hasU) phi_t += w * OBCA_KAPPA_D * mu * sl; }
+                if (q.hasU) { const double su = S.Ub[r] - st; phi_t -= w * mu * log(su); if (!q.hasL) phi_t += w * OBCA_KAPPA_D * mu * su; }
+            }
+            for (int pr = lane; pr < L.npair; pr += 64) {
+                double e1, e2;
+                rot_value(L, S.xt, S.ctt, S.stt, S.cct, pr, e1, e2);
+                th_t += fabs(e1) + fabs(e2);
+            }
+            th_t = wave_sum(th_t);
+            phi_t = wave_sum(phi_t) + f_t;
+            bool ok = false;
+            aug = false;
+            const bool finite = isfinite(phi_t) && isfinite(th_t);
+            const bool blocked = (th_t >= theta_max) || (__any(f_valid && th_t >= f_th && phi_t >= f_phi) != 0);
+            if (finite && !blocked) {
+                const bool switching = dphi < 0.0 && alpha * pow(-dphi, OBCA_S_PHI) > OBCA_DELTA * pow(th, OBCA_S_THETA);
+                if (th <= theta_min && switching) {
+                    ok = phi_t <= phi + OBCA_ETA_PHI * alpha * dphi + 10.0 * 2.220446049250313e-16 * fabs(phi);
+                } else {
+                    ok = (th_t <= (1.0 - OBCA_GAMMA_THETA) * th) || (phi_t <= phi - OBCA_GAMMA_PHI * th);
+                    aug = ok;
+                }
+            }
+            if (ok) { accepted = true; break; }
+            alpha *= 0.5;
+            if (alpha < alpha_min) break;
+        }
+        if (!accepted) { status = OBCA_STATUS_LINESEARCH; break; }
+        if (aug) {
+            const double tn = (1.0 - OBCA_GAMMA_THETA) * th, pn = phi - OBCA_GAMMA_PHI * th;
+            if (f_valid && f_th >= tn && f_phi >= pn) f_valid = false;          // dominated entries leave
+            const unsigned long long freem = __ballot(!f_valid);
+            if (freem == 0ull) { status = OBCA_STATUS_NUMERIC; break; }
+            const int slot = __ffsll((long long)freem) - 1;
+            if (lane == slot) { f_valid = true; f_th = tn; f_phi = pn; }
+        }
+        // ---- accept ------------------------------------------------------------------------------------------
+        for (int r = lane; r < L.R; r += 64) {
+            const RowLin q = row_lin(L, S, r, mu, rho, delta_w);
+            const double dy = S.dy[r];
+            const double ds = q.eq ? 0.0 : (dy - q.rs) / q.Ds;
+            const double dp = (dy - q.rp) / q.Dp;
+            const double dn = (-dy - q.rn) / q.Dn;
+            const double lo = S.Lb[r], up = S.Ub[r];
+            const double s_old = S.s[r], p_old = S.p[r], n_old = S.n[r];
+            const double s = q.eq ? 0.0 : s_old + alpha * ds, p = p_old + alpha * dp, n = n_old + alpha * dn;
+            const double ks = OBCA_KAPPA_SIGMA;
+            if (q.hasL) {
+                const double zL = S.zL[r] + a_z * ((mu - S.zL[r] * ds) / (s_old - lo) - S.zL[r]);
+                const double sl = s - lo;
+                S.zL[r] = fmax(fmin(zL, ks * mu / sl), mu / (ks * sl));
+            }
+            if (q.hasU) {
+                const double zU = S.zU[r] + a_z * ((mu + S.zU[r] * ds) / (up - s_old) - S.zU[r]);
+                const double su = up - s;
+                S.zU[r] = fmax(fmin(zU, ks * mu / su), mu / (ks * su));
+            }
+            const double zp = S.zp[r] + a_z * ((mu - S.zp[r] * dp) / p_old - S.zp[r]);
+            const double zn = S.zn[r] + a_z * ((mu - S.zn[r] * dn) / n_old - S.zn[r]);
+            S.zp[r] = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
+            S.zn[r] = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
+            S.s[r] = s; S.p[r] = p; S.n[r] = n;
+            S.y[r] += alpha * dy;
+        }
+        for (int t = lane; t < 2 * L.npair; t += 64) S.nu[t] += alpha * S.dnu[t];
+        for (int t = lane; t < L.n; t += 64) S.x[t] = S.xt[t];
+        SYNC();
+        fobj_prev = fobj;
+        have_prev = true;
+        // ---- re-evaluate at the new iterate ------------------------------------------------------------------
+        eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
+        f = eval_objective<true>(L, S, in, S.x, sf, lane);
+        for (int r = lane; r < L.R; r += 64) S.g[r] = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
+        for (int pr = lane; pr < L.npair; pr += 64) {
+            double e1, e2;
+            rot_value(L, S.x, S.ct, S.st, S.cc, pr, e1, e2);
+            S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;
+        }
+        SYNC();
+    }
+
+    if ((status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE) && elastic_max > O.feas_tol)
+        status = OBCA_STATUS_INFEASIBLE;
+
+    // ---- outputs (last iterate on failure, like the reference's except-branch) --------------------------------
+    {
+        const int N1 = L.N + 1;
+        double* xo = A.xopt + (size_t)inst * 3 * N1;
+        double* uo = A.uopt + (size_t)inst * 2 * L.N;
+        for (int t = lane; t < 3 * N1; t += 64) { const int j = t / N1, k = t - j * N1; xo[t] = S.x[L.ip(k) + j]; }
+        for (int t = lane; t < 2 * L.N; t += 64) { const int j = t / L.N, k = t - j * L.N; uo[t] = S.x[L.iu(k) + j]; }
+        if (lane == 0) {
+            A.ts_opt[inst] = L.free_T ? S.x[L.iT()] * in.Ts : in.Ts;
+            A.status[inst] = status;
+            A.iters[inst] = it;
+            if (A.info) {
+                double* io = A.info + (size_t)inst * 4;
+                io[0] = f / sf; io[1] = elastic_max; io[2] = E0; io[3] = (double)nfact;
+            }
+        }
+    }
+}

@@ -1,0 +1,53 @@
+"""Drop-in for the reference module ``obca`` (class ``obca``; reference src/obca.py).
+
+Same positional signatures and return tuples as the reference's live variants
+    obca_mpc4  (src/obca.py:828)   free time
+    obca_mpc6  (src/obca.py:1361)  fixed time + terminal set
+    obca_mpc8  (src/obca.py:1564)  fixed time, no terminal set
+so a driver written for the reference (`self.obca_solver = obca()`, src/closed_loop.py:22) runs unchanged.
+Each call is a batch of one on the MI355X kernel; like the reference it never raises on solver failure
+and returns the last iterate with ``feas=False``.
+"""
+import numpy as np
+import torch
+
+from .solver import BatchSolver, SolverParams, pack_reference_call
+
+
+class obca:
+    def __init__(self):
+        self._solvers = {}
+
+    def _solver(self, N, m):
+        key = (int(N), tuple(m))
+        if key not in self._solvers:
+            self._solvers[key] = BatchSolver(N, m, max_batch=1)
+        return self._solvers[key]
+
+    def _run(self, variant, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0,
+             terminal_set=None):
+        m, x0v, u0v, xr, A, b, Tsv, term = pack_reference_call(variant, Ts, N, x0, xref, nObs, vObs, AObs, bObs, u0,
+                                                                terminal_set)
+        kw = dict(xL=xL, xU=xU, uL=uL, uU=uU, ego=ego, dmin=dmin)
+        if variant == 4:
+            prm = SolverParams(Q_free=Q, R_free=R, P_free=P, **kw)
+        else:
+            prm = SolverParams(Q_fix=Q, R_fix=R, P_fix=P, **kw)
+        s = self._solver(N, m)
+        out = s.solve(variant, x0v[None], u0v[None], xr[None], A[None], b[None], np.array([Tsv]), term[None], prm)
+        torch.cuda.synchronize()
+        feas = bool(out.feas[0].item())
+        x_Opt = out.xopt[0].cpu().numpy()
+        u_Opt = out.uopt[0].cpu().numpy()
+        return x_Opt, u_Opt, feas, float(out.ts_opt[0].item())
+
+    def obca_mpc4(self, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0):
+        return self._run(4, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0)
+
+    def obca_mpc6(self, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, uOpt,
+                  terminal_set):
+        return self._run(6, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0,
+                         terminal_set)
+
+    def obca_mpc8(self, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, uOpt):
+        return self._run(8, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0)
