@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- OBCA closed-loop MPC steps/sec (batch) at N=5, 3 obstacles on MI355X.
+
+One "step" = one pass of the hot path (one obca_mpc4 solve per instance) over a batch of B=8192 seeded
+synthetic instances (SURVEY.md section 8(d), config C2 at the batch size BASELINE.json quotes).  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line (see the repo contract).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the batch of independent instances is sharded, one process per GPU, B per GPU fixed (weak scaling);
+no collective on the data path, one RCCL all_gather of the outputs after the timed region plus the reductions
+needed for timing/reporting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES = {(5, 6): 1320, (5, 12): 2184, (6, 6): 1528}       # algorithmic bytes per instance-step
+HBM_PEAK_GBPS = 8000.0                                          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
+
+
+def alg_bytes(N, M):
+    return 8 * (3 + 2 + 3 * (N + 1) + 3 * M * (N + 1) + 1 + 3) + 8 * (3 * (N + 1) + 2 * N + 1) + 8
+
+
+def cpu_baseline(batch, N, seconds=20.0):
+    """Oracle (CPU restatement) timed on the host cores of this box on a bounded sample of the same workload."""
+    try:
+        from oracle import c_oracle
+        have_c = c_oracle.available()
+    except Exception:
+        have_c = False
+    cores = os.cpu_count() or 1
+    if have_c:
+        from oracle import c_oracle
+        n, t_used, solved = 0, 0.0, 0
+        chunk = max(cores, 8)
+        t0 = time.time()
+        while time.time() - t0 < seconds and n + chunk <= batch["x0"].shape[0]:
+            sl = slice(n, n + chunk)
+            st = c_oracle.solve_batch(4, N, batch["m"], batch["x0"][sl], batch["u0"][sl], batch["xref"][sl],
+                                      batch["A"][sl], batch["b"][sl], batch["Ts"][sl], None, threads=cores)["status"]
+            solved += int(np.sum((st == 0) | (st == 1)))
+            n += chunk
+        dt = time.time() - t0
+        return {"value": n / dt, "unit": "MPC steps/s", "cores": cores, "kind": "port",
+                "sample": "%d instances of the same batch, C restatement (oracle/obca_oracle.c), %d threads, %.1f s"
+                          % (n, cores, dt), "solved": solved}
+    from oracle import ipm_dense
+    from oracle.obca_nlp import Problem
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    n = 0
+    t0 = time.time()
+    while time.time() - t0 < seconds and n < batch["x0"].shape[0]:
+        p = Problem(4, N, batch["m"], batch["x0"][n], batch["u0"][n], batch["xref"][n], batch["A"][n], batch["b"][n],
+                    sc.TS, 0.1 * np.eye(3), 0.01 * np.eye(2), 0.1 * np.eye(2), 0.1 * np.eye(3), sc.XL, sc.XU,
+                    [-0.6, -np.pi / 6], [0.6, np.pi / 6], sc.EGO, sc.DMIN)
+        ipm_dense.solve(p, {"max_soc": 0})
+        n += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "MPC steps/s", "cores": 1, "kind": "port",
+            "sample": "%d instances of the same batch, numpy dense restatement (oracle/ipm_dense.py), %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8192, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=5)
+    ap.add_argument("--three-boxes", action="store_true", help="M=12 sub-config (3 boxes) instead of walls+box (M=6)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+
+    B, N = args.batch, args.horizon
+    batch = sc.make_batch(B, N, three_boxes=args.three_boxes, first=rank * B)      # shard: instances rank*B ..
+    M = sum(batch["m"])
+    solver = BatchSolver(N, batch["m"], max_batch=B, device=dev)
+    prm = SolverParams()
+    dv = {k: torch.as_tensor(batch[k], device=dev) for k in ("variant", "x0", "u0", "xref", "A", "b", "Ts", "term")}
+    torch.cuda.synchronize()
+
+    def step(out=None):
+        return solver.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"],
+                            prm, out=out)
+
+    out = None
+    for _ in range(args.warmup):
+        out = step(out)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()                       # same stream the kernel is launched on (torch's current stream)
+        out = step(out)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    ok = ((out.status == 0) | (out.status == 1)).sum().to(torch.float64)
+    stats = torch.stack([torch.tensor(elapsed, dtype=torch.float64, device=dev), ok,
+                         out.iters.to(torch.float64).sum(), out.info[:, 3].sum()])
+    if dist:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax.item())
+        gathered = [torch.empty_like(out.xopt) for _ in range(world)]          # the one data collective: outputs
+        dist.all_gather(gathered, out.xopt)
+    n_ok, it_sum, nf_sum = float(stats[1]), float(stats[2]), float(stats[3])
+    total = B * world
+
+    if rank == 0:
+        value = total * args.steps / elapsed
+        ab = alg_bytes(N, M)
+        achieved = ab * B / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "OBCA MPC steps/sec (batch) at N=5, 3 obs", "value": value, "unit": "MPC steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2 generator (SURVEY 8d): demo1 corridor, 2 wall rows + 1 random box (M=%d), "
+                                   "random start along an A*-like lattice path, obca_mpc4 cold start, seed %d"
+                                   % (M, sc.SEED0),
+                       "batch_per_gpu": B, "horizon_N": N, "obstacles": 3, "variant": "obca_mpc4",
+                       "parallelism": "shard%d" % world},
+            "success_rate": n_ok / total, "mean_ipm_iters": it_sum / total, "mean_kkt_factorisations": nf_sum / total,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "obca_ipm_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_instance": ab,
+                         "note": "latency/fp64-VALU bound by design (SURVEY 8d): ~1.3 KB of HBM traffic per solve"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

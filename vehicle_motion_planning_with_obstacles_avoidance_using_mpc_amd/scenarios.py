@@ -1,0 +1,168 @@
+"""Seeded synthetic workloads of SURVEY.md section 8(d) (configs C2 / C4): random start poses in the demo1
+corridor with one random box, A*-like lattice reference, N+1-point window, obca_mpc4 inputs.
+
+World: corridor ``xL=[0,0]``, ``xU=[39,10]`` with walls y >= 9 and y <= 1 (one half-space each, exactly the
+rows the reference derives for demo1: src/demo_setting.py:93-95 -> src/model_obstacle.py:37-102) and one
+axis-aligned box.  Instance ``i`` uses ``numpy.random.default_rng(seed0 + i)``; windows whose start or terminal
+pose is in collision, or whose time-scale bound ``max_Topt`` (signed sum, src/obca.py:961-962) cannot cover
+the window length, are redrawn from the same generator, so the batch is reproducible from ``seed0`` alone.
+"""
+import math
+
+import numpy as np
+
+from .model_obstacle import obstacleModel, rectangle_vertices
+
+SEED0 = 20260928
+XL, XU = (0.0, 0.0), (39.0, 10.0)
+EGO = (1.7, 0.75, 1.7, 0.75)
+DMIN = 0.05
+TS = 0.1
+V_MAX = 0.6
+
+
+def lattice_path(y0, box, y_goal=None):
+    """8-connected polyline of 1 m steps from x=3 to x=38, detouring round ``box`` = (cx, cy, l, w)."""
+    cx, cy, l, w = box
+    x_lo, x_hi = cx - l / 2, cx + l / 2
+    y_lo, y_hi = cy - w / 2, cy + w / 2
+    need = 0.75 + DMIN + 0.55                       # half width + clearance + margin
+    blocked = (y_lo - need) < y0 < (y_hi + need)
+    y_det = y0
+    if blocked:
+        up = math.ceil(y_hi + need)
+        dn = math.floor(y_lo - need)
+        cands = [y for y in (up, dn) if 2 <= y <= 8]
+        if not cands:
+            return None
+        y_det = min(cands, key=lambda y: abs(y - y0))
+    pts = []
+    x, y = 3, y0
+    x_start_det = math.floor(x_lo - 2.5) - abs(y_det - y0)        # diagonal finishes ~2.5 m before the box
+    x_end_det = math.ceil(x_hi + 2.5)
+    while x <= 38:
+        pts.append((float(x), float(y)))
+        if blocked and x >= x_start_det and x < x_end_det and y != y_det:
+            y += 1 if y_det > y else -1
+        elif blocked and x >= x_end_det and y != y0:
+            y += 1 if y0 > y else -1
+        x += 1
+    if blocked and x_start_det < 3:
+        return None
+    path = np.zeros((3, len(pts)))
+    path[0] = [p[0] for p in pts]
+    path[1] = [p[1] for p in pts]
+    for i in range(len(pts) - 1):                                  # yaw rule of a_star.create_reference_path
+        path[2, i] = math.atan2(path[1, i + 1] - path[1, i], path[0, i + 1] - path[0, i])
+    path[2, -1] = path[2, -2]
+    return path
+
+
+def window(path, pose, N):
+    """closest-point window (reference closedLoop.update_reference_trajectory, src/closed_loop.py:502-528)"""
+    d = (pose[0] - path[0]) ** 2 + (pose[1] - path[1]) ** 2
+    i0 = int(np.argmin(d))                                          # first minimum, like the strict '<' loop
+    P = path.shape[1]
+    idx = np.minimum(i0 + np.arange(N + 1), P - 1)
+    return path[:, idx].copy()
+
+
+def _car_corners(pose):
+    x, y, th = pose
+    c, s = math.cos(th), math.sin(th)
+    out = []
+    for dx, dy in ((EGO[0], EGO[1]), (EGO[0], -EGO[3]), (-EGO[2], -EGO[3]), (-EGO[2], EGO[1])):
+        out.append((x + c * dx - s * dy, y + s * dx + c * dy))
+    return np.array(out)
+
+
+def _poly_distance(Pa, Pb):
+    """distance between two convex polygons (vertex arrays); 0 when they overlap"""
+    best = 0.0
+    for poly, other in ((Pa, Pb), (Pb, Pa)):
+        n = len(poly)
+        for i in range(n):
+            e = poly[(i + 1) % n] - poly[i]
+            nrm = np.array([e[1], -e[0]])
+            ln = np.linalg.norm(nrm)
+            if ln == 0:
+                continue
+            nrm = nrm / ln
+            if np.max((poly - poly[i]) @ nrm) > 1e-12:
+                nrm = -nrm
+            gap = np.min((other - poly[i]) @ nrm)
+            best = max(best, gap)
+    if best > 0:                                                    # separated: refine with vertex-edge distances
+        dmin = np.inf
+        for A, B in ((Pa, Pb), (Pb, Pa)):
+            for p in A:
+                for i in range(len(B)):
+                    a, b = B[i], B[(i + 1) % len(B)]
+                    t = np.clip(np.dot(p - a, b - a) / max(np.dot(b - a, b - a), 1e-300), 0, 1)
+                    dmin = min(dmin, np.linalg.norm(p - (a + t * (b - a))))
+        return dmin
+    return 0.0
+
+
+def clearance(pose, box):
+    car = _car_corners(pose)
+    cx, cy, l, w = box
+    bx = np.array([[cx - l / 2, cy - w / 2], [cx - l / 2, cy + w / 2], [cx + l / 2, cy + w / 2],
+                   [cx + l / 2, cy - w / 2]])
+    d = _poly_distance(car, bx)
+    d = min(d, 9.0 - np.max(car[:, 1]), np.min(car[:, 1]) - 1.0)
+    return d
+
+
+def make_instance(i, N=5, seed0=SEED0, three_boxes=False):
+    rng = np.random.default_rng(seed0 + i)
+    om = obstacleModel()
+    for _ in range(200):
+        box = (rng.uniform(12, 30), rng.uniform(2.5, 7.5), rng.uniform(2, 5), rng.uniform(2, 5))
+        y0 = int(round(rng.uniform(2, 8)))
+        path = lattice_path(y0, box)
+        noise = rng.uniform([-0.3, -0.3, -0.2], [0.3, 0.3, 0.2])
+        u0 = np.array([rng.uniform(0, 0.6), rng.uniform(-0.1, 0.1)])
+        if path is None:
+            continue
+        i0 = int(rng.integers(0, path.shape[1] - N - 1))
+        x0 = path[:, i0] + noise
+        xref = window(path, x0, N)
+        seg = np.diff(xref[:2], axis=1)
+        length = float(np.sum(np.hypot(seg[0], seg[1]))) + float(np.hypot(*(xref[:2, 0] - x0[:2])))
+        dis = (xref[0, N] - x0[0]) + (xref[1, N] - x0[1])
+        tmax = dis / (N * V_MAX * TS) + 1.0
+        if tmax < 1.15 * length / (N * V_MAX * TS):
+            continue
+        if clearance(x0, box) < DMIN + 0.1 or clearance(xref[:, N], box) < DMIN + 0.1:
+            continue
+        if abs(xref[2, N] - x0[2]) > 1.0:
+            continue
+        rect = rectangle_vertices(box[0], box[1], 0.0, box[2], box[3])
+        if three_boxes:
+            polys = [[[39, 9], [0, 9], [0, 10], [39, 10], [39, 9]], rect, [[0, 1], [39, 1], [39, 0], [0, 0], [0, 1]]]
+        else:
+            polys = [[[39, 9], [0, 9]], rect, [[0, 1], [39, 1]]]          # demo1-style walls (1 row each)
+        v = [len(p) for p in polys]
+        A, b = om.obstacle_H_Represent(len(polys), v, polys)
+        return dict(x0=x0, u0=u0, xref=xref, A=A, b=b[:, 0], m=[n - 1 for n in v], box=box, path=path)
+    raise RuntimeError("could not draw a feasible instance for seed %d" % (seed0 + i))
+
+
+def make_batch(B, N=5, seed0=SEED0, three_boxes=False, first=0):
+    """Arrays in the layout of include/obca_mpc.h for instances first .. first+B-1 (variant 4)."""
+    ins = [make_instance(first + i, N, seed0, three_boxes) for i in range(B)]
+    m = ins[0]["m"]
+    M = sum(m)
+    out = dict(
+        m=m,
+        variant=np.full(B, 4, dtype=np.int32),
+        x0=np.stack([q["x0"] for q in ins]),
+        u0=np.stack([q["u0"] for q in ins]),
+        xref=np.stack([q["xref"] for q in ins]),
+        A=np.stack([np.broadcast_to(q["A"], (N + 1, M, 2)) for q in ins]).copy(),
+        b=np.stack([np.broadcast_to(q["b"], (N + 1, M)) for q in ins]).copy(),
+        Ts=np.full(B, TS),
+        term=np.zeros((B, 3)),
+    )
+    return out
