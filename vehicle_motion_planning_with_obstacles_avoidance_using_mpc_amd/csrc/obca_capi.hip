@@ -11,7 +11,7 @@ extern "C" __global__ void obca_ipm_kernel(ObcaLaunch A);
 
 struct obca_handle {
     obca_dims dims;
-    int32_t M, n_max, R_max;
+    int32_t M, n_max, R_max, inst_off;
     int32_t offm[OBCA_MAX_OBST + 1];
     int64_t lds_bytes;
 };
@@ -30,7 +30,7 @@ bool dims_ok(const obca_dims* d) {
 }
 
 // must mirror the carve-up in obca_kernel.hip
-int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max) {
+int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off) {
     const int N1 = N + 1, np = N1 * nO;
     n_max = N1 * (3 + M + 4 * nO) + 2 * N + 1;
     R_max = 3 + 3 * N + 3 + 2 * N1 + 2 * N + 2 * N + 2 + 2 * np + N1 * M + N1 * 4 * nO;
@@ -44,6 +44,9 @@ int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max) {
     take(64 * N1); take(8 * N1); take(12 * np); take(MW * 4 * np);
     take(36 * N1); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
     take(36); take(6); take(48); take(6); take(48); take(6); take(64); take(8); take(8);
+    take(8);                 // offm
+    inst_off = (int)t;
+    take(OBCA_INST_DOUBLES);
     return t;
 }
 
@@ -53,8 +56,8 @@ extern "C" int64_t obca_lds_bytes(const obca_dims* d) {
     if (!dims_ok(d)) return -1;
     int M = 0;
     for (int i = 0; i < d->n_obs; ++i) M += d->m[i];
-    int n_max, R_max;
-    return 8 * lds_doubles(d->N, d->n_obs, M, n_max, R_max);
+    int n_max, R_max, io;
+    return 8 * lds_doubles(d->N, d->n_obs, M, n_max, R_max, io);
 }
 
 extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
@@ -70,7 +73,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
         if (i < d->n_obs) h->M += d->m[i];
         h->offm[i + 1] = h->M;
     }
-    h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max);
+    h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
     if (h->lds_bytes > 160 * 1024) { delete h; return OBCA_E_LDS; }
     if (hipSetDevice(d->device) != hipSuccess) { delete h; return OBCA_E_HIP; }
     if (h->lds_bytes > 64 * 1024) {
@@ -99,7 +102,7 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     if (B == 0) return OBCA_OK;
     ObcaLaunch L;
     memset(&L, 0, sizeof(L));
-    L.B = B; L.N = h->dims.N; L.nO = h->dims.n_obs; L.M = h->M; L.n_max = h->n_max; L.R_max = h->R_max;
+    L.B = B; L.N = h->dims.N; L.nO = h->dims.n_obs; L.M = h->M; L.n_max = h->n_max; L.R_max = h->R_max; L.inst_off = h->inst_off;
     for (int i = 0; i <= OBCA_MAX_OBST; ++i) L.offm[i] = h->offm[i];
     L.variant = variant; L.x0 = x0; L.u0 = u0; L.xref = xref; L.A = A; L.b = b; L.Ts = Ts; L.term = term;
     L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info;

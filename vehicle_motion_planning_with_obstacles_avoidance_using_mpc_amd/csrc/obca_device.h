@@ -39,6 +39,8 @@
 #define OBCA_MAX_GRADIENT 100.0
 #define OBCA_ACCEPTABLE_ITER 15
 
+#define OBCA_INST_DOUBLES 64   /* LDS reserved for the per-instance constant block (struct Inst) */
+
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
 struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed; };
 struct ObcaParamsDev {
@@ -49,7 +51,7 @@ struct ObcaParamsDev {
 };
 
 struct ObcaLaunch {
-    int32_t B, N, nO, M, n_max, R_max;
+    int32_t B, N, nO, M, n_max, R_max, inst_off;
     int32_t offm[OBCA_MAX_OBST + 1];
     const int32_t* variant;
     const double *x0, *u0, *xref, *A, *b, *Ts, *term;

@@ -52,7 +52,6 @@ struct Lay {
     int N, nO, M, NS, n, free_T, variant;
     int r_init, r_dyn, r_term, r_xb, r_ub, r_acc, r_T, r_tx, r_norm, r_dist, r_lam, r_mu, R;
     int npair;
-    int offm[OBCA_MAX_OBST + 1];
     __device__ __forceinline__ int ip(int k) const { return k * NS; }
     __device__ __forceinline__ int iu(int k) const { return k * NS + 3; }
     __device__ __forceinline__ int il(int k) const { return k * NS + (k < N ? 5 : 3); }
@@ -66,6 +65,8 @@ struct Inst {             // per-instance constants (registers, wave-uniform)
     double Q[9], P[9], R1[4], R2[4];
 };
 
+static_assert(sizeof(Inst) <= OBCA_INST_DOUBLES * sizeof(double), "Inst does not fit its LDS slot");
+
 // LDS carve-up (all doubles)
 struct Sh {
     double *x, *xt, *dx, *gf, *rx, *bx;
@@ -77,6 +78,7 @@ struct Sh {
     double *Pk, *qk, *Kk, *kapk, *Mik;
     double *X, *qt, *FG, *fv, *Z, *zv, *Mall, *mall;
     double *red;
+    int* offm;
 };
 
 __device__ __forceinline__ double dmaxabs(double a, double b) { return fmax(a, fabs(b)); }
@@ -100,7 +102,7 @@ __device__ void eval_geom(const Lay& L, const Sh& S, const double* xv, double* c
     }
     for (int pr = lane; pr < L.npair; pr += 64) {
         const int k = pr / L.nO, i = pr - k * L.nO;
-        const int o0 = L.offm[i], o1 = L.offm[i + 1];
+        const int o0 = S.offm[i], o1 = S.offm[i + 1];
         const double* lam = xv + L.il(k);
         const double* A = S.Aobs + (size_t)k * L.M * 2;
         double c0 = 0.0, c1 = 0.0;
@@ -160,7 +162,7 @@ __device__ double row_value(const Lay& L, const Sh& S, const Inst& in, const dou
         const double* b = S.bobs + (size_t)k * L.M;
         double v = -(in.gego[0] * mu[0] + in.gego[1] * mu[1] + in.gego[2] * mu[2] + in.gego[3] * mu[3]) +
                    tx * cc[2 * pr] + ty * cc[2 * pr + 1];
-        for (int j = L.offm[i]; j < L.offm[i + 1]; ++j) v -= b[j] * lam[j];
+        for (int j = S.offm[i]; j < S.offm[i + 1]; ++j) v -= b[j] * lam[j];
         return v;
     }
     if (r < L.r_mu) {
@@ -308,7 +310,7 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
     for (int t = lane; t < (L.N + 1) * L.M; t += 64) {
         const int k = t / L.M, j = t - k * L.M;
         int i = 0;
-        while (j >= L.offm[i + 1]) ++i;
+        while (j >= S.offm[i + 1]) ++i;
         const int pr = k * L.nO + i;
         const double a0 = S.Aobs[((size_t)k * L.M + j) * 2], a1 = S.Aobs[((size_t)k * L.M + j) * 2 + 1];
         const double cs = S.ct[k], sn = S.st[k], c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
@@ -375,7 +377,7 @@ __device__ double row_jdx(const Lay& L, const Sh& S, const Inst& in, int r) {
         const double* A = S.Aobs + (size_t)k * L.M * 2;
         const double* dl = d + L.il(k);
         double s0 = 0.0, s1 = 0.0, sb = 0.0;
-        for (int j = L.offm[i]; j < L.offm[i + 1]; ++j) {
+        for (int j = S.offm[i]; j < S.offm[i + 1]; ++j) {
             s0 += A[2 * j] * dl[j];
             s1 += A[2 * j + 1] * dl[j];
             sb += S.bobs[(size_t)k * L.M + j] * dl[j];
@@ -586,7 +588,7 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
     int bad = 0;
     for (int pr = lane; pr < L.npair; pr += 64) {
         const int k = pr / L.nO, i = pr - k * L.nO;
-        const int o0 = L.offm[i], m = L.offm[i + 1] - o0;
+        const int o0 = S.offm[i], m = S.offm[i + 1] - o0;
         const double cs = S.ct[k], sn = S.st[k];
         const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
         const double* pk = S.x + L.ip(k);
@@ -594,15 +596,11 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
         const double yn = S.y[L.r_norm + pr], En = S.Einv[L.r_norm + pr];
         const double yd = S.y[L.r_dist + pr], Ed = S.Einv[L.r_dist + pr];
         const double nu1 = S.nu[2 * pr], nu2 = S.nu[2 * pr + 1];
-        double a0[OBCA_MAX_EDGES], a1[OBCA_MAX_EDGES], gn[NW], gd[NW];
-        double K[MW][MW], G[MW][3], rl[MW];
-#pragma unroll
-        for (int a = 0; a < MW; ++a) {
-#pragma unroll
-            for (int b = 0; b < MW; ++b) K[a][b] = 0.0;
-            G[a][0] = G[a][1] = G[a][2] = 0.0;
-            rl[a] = 0.0;
-        }
+        // Packed lower-triangular K (MW*(MW+1)/2 registers); Yv starts as [G | rloc] and is solved in place.
+        double a0[OBCA_MAX_EDGES], a1[OBCA_MAX_EDGES], gn[OBCA_MAX_EDGES], gd[NW];
+        double K[MW * (MW + 1) / 2], Yv[MW][4];
+#define KP(a, b) K[((a) * ((a) + 1)) / 2 + (b)]
+        const double dth = -sn * c0 + cs * c1;          // d(dist)/d(theta) / off  and  d(e1)/d(theta)
 #pragma unroll
         for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
             const bool on = j < m;
@@ -613,85 +611,74 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
             gd[j] = on ? (tx * a0[j] + ty * a1[j] - bj) : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { gn[OBCA_MAX_EDGES + j] = 0.0; gd[OBCA_MAX_EDGES + j] = -in.gego[j]; }
-        // primal block
+        for (int j = 0; j < 4; ++j) gd[OBCA_MAX_EDGES + j] = -in.gego[j];
+        // primal block (lower triangle)
 #pragma unroll
         for (int a = 0; a < NW; ++a)
 #pragma unroll
-            for (int b = 0; b < NW; ++b) {
-                double v = En * gn[a] * gn[b] + Ed * gd[a] * gd[b];
-                if (a < OBCA_MAX_EDGES && b < OBCA_MAX_EDGES) v += yn * 2.0 * (a0[a] * a0[b] + a1[a] * a1[b]);
-                K[a][b] = v;
-            }
+            for (int b = 0; b < NW; ++b)
+                if (b <= a) {
+                    double v = Ed * gd[a] * gd[b];
+                    if (a < OBCA_MAX_EDGES) v += En * gn[a] * gn[b] + yn * 2.0 * (a0[a] * a0[b] + a1[a] * a1[b]);
+                    KP(a, b) = v;
+                }
 #pragma unroll
         for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
             const bool on = j < m;
-            K[j][j] += on ? (dw + S.Einv[L.r_lam + k * L.M + o0 + j]) : 1.0;   // padded slots: identity
-            rl[j] = on ? -S.bx[L.il(k) + o0 + j] : 0.0;
-            // coupling to the pose: rows (x, y, theta)
-            G[j][0] = Ed * gd[j] * c0 + yd * a0[j];
-            G[j][1] = Ed * gd[j] * c1 + yd * a1[j];
-            G[j][2] = Ed * gd[j] * in.off * (-sn * c0 + cs * c1) + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
-                      nu1 * (-sn * a0[j] + cs * a1[j]) + nu2 * (-cs * a0[j] - sn * a1[j]);
+            KP(j, j) += on ? (dw + S.Einv[L.r_lam + k * L.M + o0 + j]) : 1.0;   // padded slots: identity
+            Yv[j][3] = on ? -S.bx[L.il(k) + o0 + j] : 0.0;
+            // coupling to the pose: columns (x, y, theta)
+            Yv[j][0] = Ed * gd[j] * c0 + yd * a0[j];
+            Yv[j][1] = Ed * gd[j] * c1 + yd * a1[j];
+            Yv[j][2] = Ed * gd[j] * in.off * dth + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
+                       nu1 * (-sn * a0[j] + cs * a1[j]) + nu2 * (-cs * a0[j] - sn * a1[j]);
             // rotation rows
-            K[NW][j] = K[j][NW] = cs * a0[j] + sn * a1[j];
-            K[NW + 1][j] = K[j][NW + 1] = -sn * a0[j] + cs * a1[j];
+            KP(NW, j) = cs * a0[j] + sn * a1[j];
+            KP(NW + 1, j) = -sn * a0[j] + cs * a1[j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int a = OBCA_MAX_EDGES + j;
-            K[a][a] += dw + S.Einv[L.r_mu + k * 4 * L.nO + 4 * i + j];
-            rl[a] = -S.bx[L.imu(k) + 4 * i + j];
-            G[a][0] = Ed * gd[a] * c0;
-            G[a][1] = Ed * gd[a] * c1;
-            G[a][2] = Ed * gd[a] * in.off * (-sn * c0 + cs * c1);
+            KP(a, a) += dw + S.Einv[L.r_mu + k * 4 * L.nO + 4 * i + j];
+            Yv[a][3] = -S.bx[L.imu(k) + 4 * i + j];
+            Yv[a][0] = Ed * gd[a] * c0;
+            Yv[a][1] = Ed * gd[a] * c1;
+            Yv[a][2] = Ed * gd[a] * in.off * dth;
+            KP(NW, a) = (j == 0) ? 1.0 : (j == 2) ? -1.0 : 0.0;
+            KP(NW + 1, a) = (j == 1) ? 1.0 : (j == 3) ? -1.0 : 0.0;
         }
-        K[NW][OBCA_MAX_EDGES + 0] = K[OBCA_MAX_EDGES + 0][NW] = 1.0;
-        K[NW][OBCA_MAX_EDGES + 2] = K[OBCA_MAX_EDGES + 2][NW] = -1.0;
-        K[NW + 1][OBCA_MAX_EDGES + 1] = K[OBCA_MAX_EDGES + 1][NW + 1] = 1.0;
-        K[NW + 1][OBCA_MAX_EDGES + 3] = K[OBCA_MAX_EDGES + 3][NW + 1] = -1.0;
-        G[NW][2] = -sn * c0 + cs * c1;
-        G[NW + 1][2] = -cs * c0 - sn * c1;
-        rl[NW] = -S.crot[2 * pr];
-        rl[NW + 1] = -S.crot[2 * pr + 1];
-        // LDL^T without pivoting (quasi-definite when the primal block is positive definite)
-        double Yv[MW][4];
-#pragma unroll
-        for (int a = 0; a < MW; ++a) { Yv[a][0] = G[a][0]; Yv[a][1] = G[a][1]; Yv[a][2] = G[a][2]; Yv[a][3] = rl[a]; }
+        KP(NW, NW) = 0.0; KP(NW + 1, NW) = 0.0; KP(NW + 1, NW + 1) = 0.0;
+        Yv[NW][0] = 0.0; Yv[NW][1] = 0.0; Yv[NW][2] = dth; Yv[NW][3] = -S.crot[2 * pr];
+        Yv[NW + 1][0] = 0.0; Yv[NW + 1][1] = 0.0; Yv[NW + 1][2] = -cs * c0 - sn * c1; Yv[NW + 1][3] = -S.crot[2 * pr + 1];
+        // LDL^T without pivoting (quasi-definite when the primal block is positive definite),
+        // forward substitution of the four right-hand sides fused into the elimination
         double dinv[MW];
+        // rectangular constant-trip loops with predicates: after full unrolling every index is a literal,
+        // so K and Yv live in registers (triangular bounds defeat the unroller and force them to scratch)
 #pragma unroll
         for (int j = 0; j < MW; ++j) {
-            const double d = K[j][j];
+            const double d = KP(j, j);
             if (j < NW ? !(d > 0.0) : !(d < 0.0)) bad = 1;
             dinv[j] = 1.0 / d;
 #pragma unroll
-            for (int a = j + 1; a < MW; ++a) {          // trailing update with the unscaled column
-                const double la = K[a][j] * dinv[j];
+            for (int a = 0; a < MW; ++a) {
+                if (a > j) {
+                    const double la = KP(a, j) * dinv[j];
 #pragma unroll
-                for (int b = j + 1; b <= a; ++b) K[a][b] -= la * K[b][j];
+                    for (int b = 0; b < MW; ++b)
+                        if (b > j && b <= a) KP(a, b) -= la * KP(b, j);
+                }
             }
 #pragma unroll
-            for (int a = j + 1; a < MW; ++a) {
-                K[a][j] *= dinv[j];
+            for (int a = 0; a < MW; ++a) {
+                if (a > j) {
+                    KP(a, j) *= dinv[j];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) Yv[a][c] -= K[a][j] * Yv[j][c];       // forward substitution
-            }
-        }
-#pragma unroll
-        for (int j = MW - 1; j >= 0; --j) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double v = Yv[j][c] * dinv[j];
-#pragma unroll
-                for (int a = j + 1; a < MW; ++a) v -= K[a][j] * Yv[a][c];
-                Yv[j][c] = v;
+                    for (int c = 0; c < 4; ++c) Yv[a][c] -= KP(a, j) * Yv[j][c];
+                }
             }
         }
-        double* Yo = S.Y + (size_t)pr * (MW * 4);
-#pragma unroll
-        for (int a = 0; a < MW; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) Yo[4 * a + c] = Yv[a][c];
+        // Schur complement G' Kloc^-1 [G | rloc] = Z' D^-1 Z with Z = L^-1 [G | rloc]
         double* So = S.Sloc + (size_t)pr * 12;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -699,9 +686,27 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
             for (int c = 0; c < 4; ++c) {
                 double v = 0.0;
 #pragma unroll
-                for (int e = 0; e < MW; ++e) v += G[e][a] * Yv[e][c];
+                for (int e = 0; e < MW; ++e) v += Yv[e][a] * dinv[e] * Yv[e][c];
                 So[4 * a + c] = v;
             }
+#pragma unroll
+        for (int jj = 0; jj < MW; ++jj) {
+            const int j = MW - 1 - jj;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double v = Yv[j][c] * dinv[j];
+#pragma unroll
+                for (int a = 0; a < MW; ++a)
+                    if (a > j) v -= KP(a, j) * Yv[a][c];
+                Yv[j][c] = v;
+            }
+        }
+#undef KP
+        double* Yo = S.Y + (size_t)pr * (MW * 4);
+#pragma unroll
+        for (int a = 0; a < MW; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Yo[4 * a + c] = Yv[a][c];
     }
     SYNC();
     // fold the Schur complements into the stage blocks
@@ -732,14 +737,17 @@ __device__ __forceinline__ int inv3_ipe(const double* P, int ld, const double* E
     for (int j = 0; j < 3; ++j) {
         if (!(A[3 * j + j] > 0.0)) bad = 1;
 #pragma unroll
-        for (int i = j + 1; i < 3; ++i) {
-            const double f = A[3 * i + j] / A[3 * j + j];
+        for (int i = 0; i < 3; ++i) {
+            if (i > j) {
+                const double f = A[3 * i + j] / A[3 * j + j];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { A[3 * i + c] -= f * A[3 * j + c]; Mi[3 * i + c] -= f * Mi[3 * j + c]; }
+                for (int c = 0; c < 3; ++c) { A[3 * i + c] -= f * A[3 * j + c]; Mi[3 * i + c] -= f * Mi[3 * j + c]; }
+            }
         }
     }
 #pragma unroll
-    for (int j = 2; j >= 0; --j) {
+    for (int jj = 0; jj < 3; ++jj) {
+        const int j = 2 - jj;
         const double inv = 1.0 / A[3 * j + j];
 #pragma unroll
         for (int c = 0; c < 3; ++c) Mi[3 * j + c] *= inv;
@@ -756,9 +764,13 @@ __device__ __forceinline__ int inv3_ipe(const double* P, int ld, const double* E
 
 // soft-min of V(p', o) = 1/2 [p';o]'P[p';o] + q'[p';o] against 1/2 (p'-phat)' E^-1 (p'-phat); writes X, qt
 __device__ int soft_min(const Sh& S, const double* P, const double* q, const double* E, double* MiOut, int lane) {
-    double Mi[9];
-    const int bad = inv3_ipe(P, 6, E, Mi);
-    if (lane < 9) MiOut[lane] = Mi[lane];
+    double Mr[9];
+    const int bad = inv3_ipe(P, 6, E, Mr);
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+        if (lane == c) MiOut[c] = Mr[c];           // static register index; rows are re-read from LDS below
+    SYNC();
+    const double* Mi = MiOut;
     if (lane < 36) {
         const int a = lane / 6, b = lane - 6 * a;
         double v;
@@ -984,7 +996,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     // local recovery: [dw; dnu] = Y_r - Y_G dp_k
     for (int pr = lane; pr < L.npair; pr += 64) {
         const int k = pr / L.nO, i = pr - k * L.nO;
-        const int o0 = L.offm[i], m = L.offm[i + 1] - o0;
+        const int o0 = S.offm[i], m = S.offm[i + 1] - o0;
         const double* Yo = S.Y + (size_t)pr * (MW * 4);
         const double* d = S.dx + L.ip(k);
         for (int a = 0; a < MW; ++a) {
@@ -1016,7 +1028,6 @@ obca_ipm_kernel(ObcaLaunch A) {
     L.NS = 5 + L.M + 4 * L.nO;
     L.n = (L.N + 1) * (3 + L.M + 4 * L.nO) + 2 * L.N + L.free_T;
     L.npair = (L.N + 1) * L.nO;
-    for (int i = 0; i <= OBCA_MAX_OBST; ++i) L.offm[i] = A.offm[i];
     L.r_init = 0; L.r_dyn = 3; L.r_term = 3 + 3 * L.N;
     L.r_xb = L.r_term + (L.variant == 4 ? 3 : 0);
     L.r_ub = L.r_xb + 2 * (L.N + 1);
@@ -1046,19 +1057,27 @@ obca_ipm_kernel(ObcaLaunch A) {
         S.Pk = take(36 * N1); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
         S.X = take(36); S.qt = take(6); S.FG = take(48); S.fv = take(6); S.Z = take(48); S.zv = take(6);
         S.Mall = take(64); S.mall = take(8); S.red = take(8);
+        S.offm = reinterpret_cast<int*>(take(8));
+    }
+    Inst& in = *reinterpret_cast<Inst*>(smem + A.inst_off);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i <= OBCA_MAX_OBST; ++i) S.offm[i] = A.offm[i];     // static indices: A stays in kernarg
     }
 
     // ---- instance data ----------------------------------------------------------------------------------
-    Inst in;
-    const ObcaWeightsDev& Wt = L.free_T ? A.prm.free_time : A.prm.fixed_time;
-    for (int j = 0; j < 9; ++j) { in.Q[j] = Wt.Q[j]; in.P[j] = Wt.P[j]; }
-    for (int j = 0; j < 4; ++j) { in.R1[j] = Wt.R1[j]; in.R2[j] = Wt.R2[j]; in.gego[j] = A.prm.gego[j]; }
-    for (int j = 0; j < 2; ++j) { in.xL[j] = A.prm.xL[j]; in.xU[j] = A.prm.xU[j]; in.uL[j] = A.prm.uL[j]; in.uU[j] = A.prm.uU[j]; }
-    in.off = A.prm.off; in.dmin = A.prm.dmin;
-    for (int j = 0; j < 3; ++j) in.x0[j] = A.x0[(size_t)inst * 3 + j];
-    for (int j = 0; j < 2; ++j) in.u0[j] = A.u0[(size_t)inst * 2 + j];
-    in.Ts = A.Ts[inst];
-    for (int j = 0; j < 3; ++j) in.term[j] = (L.variant == 6) ? A.term[(size_t)inst * 3 + j] : 0.0;
+    if (lane == 0) {
+        const bool fr = L.free_T != 0;
+        for (int j = 0; j < 9; ++j) { in.Q[j] = fr ? A.prm.free_time.Q[j] : A.prm.fixed_time.Q[j]; in.P[j] = fr ? A.prm.free_time.P[j] : A.prm.fixed_time.P[j]; }
+        for (int j = 0; j < 4; ++j) { in.R1[j] = fr ? A.prm.free_time.R1[j] : A.prm.fixed_time.R1[j]; in.R2[j] = fr ? A.prm.free_time.R2[j] : A.prm.fixed_time.R2[j]; in.gego[j] = A.prm.gego[j]; }
+        for (int j = 0; j < 2; ++j) { in.xL[j] = A.prm.xL[j]; in.xU[j] = A.prm.xU[j]; in.uL[j] = A.prm.uL[j]; in.uU[j] = A.prm.uU[j]; }
+        in.off = A.prm.off; in.dmin = A.prm.dmin;
+        for (int j = 0; j < 3; ++j) in.x0[j] = A.x0[(size_t)inst * 3 + j];
+        for (int j = 0; j < 2; ++j) in.u0[j] = A.u0[(size_t)inst * 2 + j];
+        in.Ts = A.Ts[inst];
+        for (int j = 0; j < 3; ++j) in.term[j] = (L.variant == 6) ? A.term[(size_t)inst * 3 + j] : 0.0;
+    }
+    SYNC();
     {
         const int N1 = L.N + 1;
         const double* xr = A.xref + (size_t)inst * 3 * N1;
@@ -1075,8 +1094,9 @@ obca_ipm_kernel(ObcaLaunch A) {
         }
         SYNC();
         const double dis = (S.xref[0 * N1 + L.N] - in.x0[0]) + (S.xref[1 * N1 + L.N] - in.x0[1]);   // signed sum (q3)
-        in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
+        if (lane == 0) in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
     }
+    SYNC();
 
     const ObcaOptsDev& O = A.prm.opt;
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
