@@ -104,6 +104,10 @@ int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
                      double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
                      double* info, void* hip_stream);
 
+/* Diagnostic: device buffer [max_batch,12] receiving per-phase shader-clock totals of each instance.
+ * Only builds compiled with -DOBCA_PROFILE write to it; NULL (the default) disables it. */
+void obca_set_profile_buffer(obca_handle* h, double* prof);
+
 /* bytes of LDS one instance needs with these dims (<= 163840 or obca_create fails with OBCA_E_LDS) */
 int64_t obca_lds_bytes(const obca_dims* dims);
 

@@ -1,0 +1,55 @@
+"""The plain-C restatement (oracle/obca_oracle.c: dense Bunch-Kaufman KKT) follows the numpy specification
+(oracle/ipm_dense.py) iterate for iterate, and reaches the Appendix C known answers."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle, ipm_dense
+from tests.test_oracle_nlp import build
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import pack_reference_call
+
+
+def run_c(case):
+    a, v = case["inputs"], case["variant"]
+    m, x0, u0, xr, A, b, Ts, term = pack_reference_call(v, a["Ts"], a["N"], a["x0"], a["xref"], a["nObs"], a["vObs"],
+                                                        a["AObs"], a["bObs"], a["u0"], a.get("terminal_set"))
+    kw = dict(xL=a["xL"][:2], xU=a["xU"][:2], uL=a["uL"], uU=a["uU"], ego=a["ego"], dmin=a["dmin"])
+    R = a["R"]
+    kw.update(dict(Qf=a["Q"], Pf=a["P"], R1f=R[0], R2f=R[1]) if v == 4 else dict(Qx=a["Q"], Px=a["P"], R1x=R[0], R2x=R[1]))
+    return c_oracle.solve_batch(v, a["N"], m, x0[None], u0[None], xr[None], A[None], b[None], [Ts], term[None],
+                                c_oracle.default_params(**kw))
+
+
+@pytest.mark.parametrize("name", ["demo1_N6_mpc4_step0", "demo9_N5_mpc4_step0", "demo8_N5_mpc4_step0",
+                                  "demo1_N5_mpc4_step0", "slanted_asym_mpc4", "slanted_asym_mpc6", "slanted_asym_mpc8",
+                                  "demo1_dyn_mpc8"])
+def test_c_follows_numpy_spec(nlp_golden, name):
+    case = [c for c in nlp_golden if c["name"] == name][0]
+    o = run_c(case)
+    r = ipm_dense.solve(build(case), {"max_soc": 0})
+    assert int(o["status"][0]) == r.status
+    assert int(o["iters"][0]) == r.iters and int(o["info"][0, 3]) == r.nfact      # same iterate sequence
+    np.testing.assert_allclose(o["xopt"][0], r.xopt, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(o["uopt"][0], r.uopt, rtol=0, atol=1e-10)
+    assert o["ts_opt"][0] == pytest.approx(float(r.Ts_opt), abs=1e-12)
+
+
+def test_known_answers_in_c(nlp_golden):
+    for name, T, f in (("demo8_N5_mpc4_step0", 20.0, 3600.238), ("demo1_N6_mpc4_step0", 20.378864, 4334.19729),
+                       ("demo9_N5_mpc4_step0", 30.451762, 7392.01551)):
+        o = run_c([c for c in nlp_golden if c["name"] == name][0])
+        assert o["status"][0] == 0
+        assert o["ts_opt"][0] == pytest.approx(T * 0.1, abs=2e-6)
+        assert o["info"][0, 0] == pytest.approx(f, abs=2e-3)
+
+
+def test_generator_batch_threads():
+    b = sc.make_batch(8, 5)
+    o1 = c_oracle.solve_batch(4, 5, b["m"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], threads=1)
+    o4 = c_oracle.solve_batch(4, 5, b["m"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], threads=4)
+    assert np.array_equal(o1["xopt"], o4["xopt"]) and np.array_equal(o1["status"], o4["status"])
+    assert np.all((o1["status"] == 0) | (o1["status"] == 1))
+    # dynamics residual of the returned trajectories
+    x, u, h = o1["xopt"], o1["uopt"], o1["ts_opt"][:, None]
+    assert np.abs(x[:, 0, 1:] - x[:, 0, :-1] - h * u[:, 0] * np.cos(x[:, 2, :-1])).max() < 1e-7
+    assert np.abs(x[:, 2, 1:] - x[:, 2, :-1] - h * u[:, 1]).max() < 1e-7

@@ -32,7 +32,8 @@ class ObcaParams(ctypes.Structure):
                 ("max_iter_free", ctypes.c_int32), ("max_iter_fixed", ctypes.c_int32)]
 
 
-EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version")
+EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",
+           "obca_set_profile_buffer")
 
 STATUS_OK, STATUS_ACCEPTABLE, STATUS_INFEASIBLE = 0, 1, 2
 STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NUMERIC, STATUS_BAD_BOUNDS = -1, -2, -3, -4
@@ -57,6 +58,8 @@ def load():
     lib.obca_solve_batch.argtypes = [ctypes.c_void_p, i32p, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp,
                                      ctypes.POINTER(ObcaParams), vp, vp, vp, i32p, i32p, vp, vp]
     lib.obca_solve_batch.restype = ctypes.c_int
+    lib.obca_set_profile_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.obca_set_profile_buffer.restype = None
     lib.obca_lds_bytes.argtypes = [ctypes.POINTER(ObcaDims)]
     lib.obca_lds_bytes.restype = ctypes.c_int64
     lib.obca_strerror.argtypes = [ctypes.c_int]

@@ -14,6 +14,7 @@ struct obca_handle {
     int32_t M, n_max, R_max, inst_off;
     int32_t offm[OBCA_MAX_OBST + 1];
     int64_t lds_bytes;
+    double* prof;
 };
 
 namespace {
@@ -83,11 +84,14 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
             return OBCA_E_HIP;
         }
     }
+    h->prof = nullptr;
     *out = h;
     return OBCA_OK;
 }
 
 extern "C" void obca_destroy(obca_handle* h) { delete h; }
+
+extern "C" void obca_set_profile_buffer(obca_handle* h, double* prof) { if (h) h->prof = prof; }
 
 extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
                                 const double* x0, const double* u0, const double* xref,
@@ -105,7 +109,7 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     L.B = B; L.N = h->dims.N; L.nO = h->dims.n_obs; L.M = h->M; L.n_max = h->n_max; L.R_max = h->R_max; L.inst_off = h->inst_off;
     for (int i = 0; i <= OBCA_MAX_OBST; ++i) L.offm[i] = h->offm[i];
     L.variant = variant; L.x0 = x0; L.u0 = u0; L.xref = xref; L.A = A; L.b = b; L.Ts = Ts; L.term = term;
-    L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info;
+    L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info; L.prof = h->prof;
     auto cpw = [](ObcaWeightsDev& d, const obca_weights& s) {
         // the reference's double loops use Q[i,j] for every (i,j): only the symmetric part matters
         for (int a = 0; a < 3; ++a)

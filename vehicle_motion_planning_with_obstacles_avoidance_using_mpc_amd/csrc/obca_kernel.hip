@@ -20,6 +20,14 @@
 
 #define SYNC() __syncthreads()
 
+#ifdef OBCA_PROFILE
+#define PROF_DECL long long prof_t[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; long long prof_last = wall_clock64();
+#define PROF(i) { const long long t_ = wall_clock64(); prof_t[i] += t_ - prof_last; prof_last = t_; }
+#else
+#define PROF_DECL
+#define PROF(i)
+#endif
+
 namespace {
 
 constexpr int MW = OBCA_MAX_EDGES + 6;      // local block width: lambda (<=4) + mu (4) + nu (2)
@@ -1174,9 +1182,11 @@ obca_ipm_kernel(ObcaLaunch A) {
     bool have_prev = false;
     double elastic_max = 0.0;
 
+    PROF_DECL
     if (bad_bounds) status = OBCA_STATUS_BAD_BOUNDS;
     else
     for (it = 0; it <= max_iter; ++it) {
+        PROF(11)
         // ---- gradient of the Lagrangian and optimality error ------------------------------------------
         gather_grad(L, S, in, S.y, S.rx, lane);
         double rxmax = 0.0, crotmax = 0.0, nusum = 0.0, th = 0.0, pnsum = 0.0;
@@ -1204,6 +1214,7 @@ obca_ipm_kernel(ObcaLaunch A) {
             if (++acc_count >= OBCA_ACCEPTABLE_ITER) { status = OBCA_STATUS_ACCEPTABLE; break; }
         } else acc_count = 0;
         if (it == max_iter) break;
+        PROF(0)
         // ---- barrier parameter ---------------------------------------------------------------------------
         {
             const double mu_floor = O.tol / (OBCA_KAPPA_EPS + 1.0);
@@ -1215,6 +1226,7 @@ obca_ipm_kernel(ObcaLaunch A) {
                 f_valid = false;
             }
         }
+        PROF(1)
         // ---- Newton step with inertia correction -----------------------------------------------------------
         double delta_w = 0.0;
         bool first_try = true;
@@ -1231,9 +1243,13 @@ obca_ipm_kernel(ObcaLaunch A) {
             }
             SYNC();
             gather_grad(L, S, in, S.yhat, S.bx, lane);
+            PROF(2)
             assemble_stages(L, S, in, sf, delta_w, lane);
+            PROF(3)
             int bad = local_blocks(L, S, in, delta_w, lane);
+            PROF(4)
             if (!bad) bad = riccati(L, S, in, lane);
+            PROF(5)
             ++nfact;
             if (!bad) break;
             if (first_try) {
@@ -1292,6 +1308,7 @@ obca_ipm_kernel(ObcaLaunch A) {
             if (th <= theta_min) c = fmin(c, OBCA_DELTA * pow(th, OBCA_S_THETA) / pow(-dphi, OBCA_S_PHI));
             alpha_min = OBCA_GAMMA_ALPHA * c;
         } else alpha_min = OBCA_GAMMA_ALPHA * OBCA_GAMMA_THETA;
+        PROF(6)
         // ---- backtracking filter line search ---------------------------------------------------------------
         double alpha = a_max, f_t = f;
         bool accepted = false, aug = false;
@@ -1338,6 +1355,7 @@ obca_ipm_kernel(ObcaLaunch A) {
             alpha *= 0.5;
             if (alpha < alpha_min) break;
         }
+        PROF(7)
         if (!accepted) { status = OBCA_STATUS_LINESEARCH; break; }
         if (aug) {
             const double tn = (1.0 - OBCA_GAMMA_THETA) * th, pn = phi - OBCA_GAMMA_PHI * th;
@@ -1380,6 +1398,7 @@ obca_ipm_kernel(ObcaLaunch A) {
         SYNC();
         fobj_prev = fobj;
         have_prev = true;
+        PROF(8)
         // ---- re-evaluate at the new iterate ------------------------------------------------------------------
         eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
         f = eval_objective<true>(L, S, in, S.x, sf, lane);
@@ -1390,7 +1409,11 @@ obca_ipm_kernel(ObcaLaunch A) {
             S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;
         }
         SYNC();
+        PROF(9)
     }
+#ifdef OBCA_PROFILE
+    if (A.prof && lane == 0) for (int i = 0; i < 12; ++i) A.prof[(size_t)inst * 12 + i] = (double)prof_t[i];
+#endif
 
     if ((status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE) && elastic_max > O.feas_tol)
         status = OBCA_STATUS_INFEASIBLE;

@@ -32,7 +32,7 @@ def lattice_path(y0, box, y_goal=None):
     if blocked:
         up = math.ceil(y_hi + need)
         dn = math.floor(y_lo - need)
-        cands = [y for y in (up, dn) if 2 <= y <= 8]
+        cands = [y for y in (up, dn) if 3 <= y <= 7]     # rows 2 and 8 leave no room to turn next to the walls
         if not cands:
             return None
         y_det = min(cands, key=lambda y: abs(y - y0))
@@ -119,7 +119,7 @@ def make_instance(i, N=5, seed0=SEED0, three_boxes=False):
     om = obstacleModel()
     for _ in range(200):
         box = (rng.uniform(12, 30), rng.uniform(2.5, 7.5), rng.uniform(2, 5), rng.uniform(2, 5))
-        y0 = int(round(rng.uniform(2, 8)))
+        y0 = int(round(rng.uniform(3, 7)))
         path = lattice_path(y0, box)
         noise = rng.uniform([-0.3, -0.3, -0.2], [0.3, 0.3, 0.2])
         u0 = np.array([rng.uniform(0, 0.6), rng.uniform(-0.1, 0.1)])
