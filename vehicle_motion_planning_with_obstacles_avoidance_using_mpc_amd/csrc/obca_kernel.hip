@@ -33,6 +33,13 @@ namespace {
 constexpr int MW = OBCA_MAX_EDGES + 6;      // local block width: lambda (<=4) + mu (4) + nu (2)
 constexpr int NW = OBCA_MAX_EDGES + 4;      // primal part of the local block
 
+// ---------------------------------------------------------------- out-of-line math
+// fp64 log/pow/sincos expand to 150-400 instructions each; inlined at every call site they pushed the hot loop
+// past the 64 KiB instruction cache.  One shared copy each.
+__device__ __noinline__ double dlog(double x) { return log(x); }
+__device__ __noinline__ double dpow(double x, double y) { return exp(y * log(x)); }
+__device__ __noinline__ void dsincos(double x, double* s, double* c) { sincos(x, s, c); }
+
 // ---------------------------------------------------------------- wave reductions (64 lanes, butterfly)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -104,7 +111,7 @@ __device__ void eval_geom(const Lay& L, const Sh& S, const double* xv, double* c
                           int lane) {
     for (int k = lane; k <= L.N; k += 64) {
         double sn, cs;
-        sincos(xv[L.ip(k) + 2], &sn, &cs);
+        dsincos(xv[L.ip(k) + 2], &sn, &cs);
         ct[k] = cs;
         st[k] = sn;
     }
@@ -1221,7 +1228,7 @@ obca_ipm_kernel(ObcaLaunch A) {
             while (mu > mu_floor) {
                 const Err em = ipm_errors(L, S, mu, rho, rxmax, crotmax, nusum, lane);
                 if (em.E > OBCA_KAPPA_EPS * mu) break;
-                mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, pow(mu, OBCA_THETA_MU)));
+                mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, dpow(mu, OBCA_THETA_MU)));
                 tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
                 f_valid = false;
             }
@@ -1280,7 +1287,7 @@ obca_ipm_kernel(ObcaLaunch A) {
                 if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
                 const double dz = (mu - zL * ds) / sl - zL;
                 if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
-                phi -= w * mu * log(sl);
+                phi -= w * mu * dlog(sl);
                 if (!q.hasU) phi += w * OBCA_KAPPA_D * mu * sl;
             }
             if (q.hasU) {
@@ -1288,7 +1295,7 @@ obca_ipm_kernel(ObcaLaunch A) {
                 if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
                 const double dz = (mu + zU * ds) / su - zU;
                 if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
-                phi -= w * mu * log(su);
+                phi -= w * mu * dlog(su);
                 if (!q.hasL) phi += w * OBCA_KAPPA_D * mu * su;
             }
             if (dp < 0.0) a_max = fmin(a_max, -tau * p / dp);
@@ -1297,7 +1304,7 @@ obca_ipm_kernel(ObcaLaunch A) {
             const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
             if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
             if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
-            phi += w * (rho * (p + n) - mu * (log(p) + log(n)));
+            phi += w * (rho * (p + n) - mu * (dlog(p) + dlog(n)));
             dphi += w * (q.gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
         }
         for (int t = lane; t < L.n; t += 64) dphi += S.gf[t] * S.dx[t];
@@ -1305,7 +1312,7 @@ obca_ipm_kernel(ObcaLaunch A) {
         double alpha_min;
         if (dphi < 0.0) {
             double c = fmin(OBCA_GAMMA_THETA, OBCA_GAMMA_PHI * th / (-dphi));
-            if (th <= theta_min) c = fmin(c, OBCA_DELTA * pow(th, OBCA_S_THETA) / pow(-dphi, OBCA_S_PHI));
+            if (th <= theta_min) c = fmin(c, OBCA_DELTA * dpow(th, OBCA_S_THETA) / dpow(-dphi, OBCA_S_PHI));
             alpha_min = OBCA_GAMMA_ALPHA * c;
         } else alpha_min = OBCA_GAMMA_ALPHA * OBCA_GAMMA_THETA;
         PROF(6)
@@ -1327,9 +1334,9 @@ obca_ipm_kernel(ObcaLaunch A) {
                 const double nt = S.n[r] + alpha * (-dy - q.rn) / q.Dn;
                 const double gt = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
                 th_t += w * fabs(gt - st - pt + nt);
-                phi_t += w * (rho * (pt + nt) - mu * (log(pt) + log(nt)));
-                if (q.hasL) { const double sl = st - S.Lb[r]; phi_t -= w * mu * log(sl); if (!q.hasU) phi_t += w * OBCA_KAPPA_D * mu * sl; }
-                if (q.hasU) { const double su = S.Ub[r] - st; phi_t -= w * mu * log(su); if (!q.hasL) phi_t += w * OBCA_KAPPA_D * mu * su; }
+                phi_t += w * (rho * (pt + nt) - mu * (dlog(pt) + dlog(nt)));
+                if (q.hasL) { const double sl = st - S.Lb[r]; phi_t -= w * mu * dlog(sl); if (!q.hasU) phi_t += w * OBCA_KAPPA_D * mu * sl; }
+                if (q.hasU) { const double su = S.Ub[r] - st; phi_t -= w * mu * dlog(su); if (!q.hasL) phi_t += w * OBCA_KAPPA_D * mu * su; }
             }
             for (int pr = lane; pr < L.npair; pr += 64) {
                 double e1, e2;
@@ -1343,7 +1350,7 @@ obca_ipm_kernel(ObcaLaunch A) {
             const bool finite = isfinite(phi_t) && isfinite(th_t);
             const bool blocked = (th_t >= theta_max) || (__any(f_valid && th_t >= f_th && phi_t >= f_phi) != 0);
             if (finite && !blocked) {
-                const bool switching = dphi < 0.0 && alpha * pow(-dphi, OBCA_S_PHI) > OBCA_DELTA * pow(th, OBCA_S_THETA);
+                const bool switching = dphi < 0.0 && alpha * dpow(-dphi, OBCA_S_PHI) > OBCA_DELTA * dpow(th, OBCA_S_THETA);
                 if (th <= theta_min && switching) {
                     ok = phi_t <= phi + OBCA_ETA_PHI * alpha * dphi + 10.0 * 2.220446049250313e-16 * fabs(phi);
                 } else {
