@@ -7,7 +7,8 @@
 #include <string.h>
 #include "obca_device.h"
 
-extern "C" __global__ void obca_ipm_kernel(ObcaLaunch A);
+extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A);
+extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A);
 
 struct obca_handle {
     obca_dims dims;
@@ -37,13 +38,14 @@ int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off)
     R_max = 3 + 3 * N + 3 + 2 * N1 + 2 * N + 2 * N + 2 + 2 * np + N1 * M + N1 * 4 * nO;
     int64_t t = 0;
     auto take = [&](int64_t c) { t += (c + 1) & ~int64_t(1); };
-    for (int i = 0; i < 6; ++i) take(n_max);
-    for (int i = 0; i < 15; ++i) take(R_max);
+    for (int i = 0; i < 5; ++i) take(n_max);                    // x, xt, dx, gf, bx
+    for (int i = 0; i < 5; ++i) take(R_max);                    // y, Einv, yhat, gh, tmp
+    take(3 * N1 + 3);                                           // dy of the soft rows
     take(N1); take(N1); take(2 * np); take(N1); take(N1); take(2 * np);
     take(2 * np); take(2 * np); take(2 * np);
     take(N1 * M * 2); take(N1 * M); take(3 * N1);
-    take(64 * N1); take(8 * N1); take(12 * np); take(MW * 4 * np);
-    take(36 * N1); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
+    take(64 * N1); take(8 * N1); take(MW * 4 * np);
+    take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
     take(36); take(6); take(48); take(6); take(48); take(6); take(64); take(8); take(8);
     take(8);                 // offm
     inst_off = (int)t;
@@ -75,11 +77,12 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
         h->offm[i + 1] = h->M;
     }
     h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
-    if (h->lds_bytes > 160 * 1024) { delete h; return OBCA_E_LDS; }
+    if (h->lds_bytes > 160 * 1024 || h->R_max > 384) { delete h; return OBCA_E_LDS; }   // rows live in registers: <= 6 per lane
     if (hipSetDevice(d->device) != hipSuccess) { delete h; return OBCA_E_HIP; }
     if (h->lds_bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(obca_ipm_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+        const void* fn = h->R_max <= 256 ? reinterpret_cast<const void*>(obca_ipm_kernel_r4)
+                                         : reinterpret_cast<const void*>(obca_ipm_kernel_r6);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
             delete h;
             return OBCA_E_HIP;
         }
@@ -135,7 +138,10 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     L.prm.opt.feas_tol = p->feas_tol > 0 ? p->feas_tol : 1e-6;
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
-    hipLaunchKernelGGL(obca_ipm_kernel, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+    if (h->R_max <= 256)
+        hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+    else
+        hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
     if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
     return OBCA_OK;
 }

@@ -84,8 +84,8 @@ static_assert(sizeof(Inst) <= OBCA_INST_DOUBLES * sizeof(double), "Inst does not
 
 // LDS carve-up (all doubles)
 struct Sh {
-    double *x, *xt, *dx, *gf, *rx, *bx;
-    double *s, *p, *n, *y, *zL, *zU, *zp, *zn, *g, *Einv, *yhat, *gh, *dy, *Lb, *Ub;
+    double *x, *xt, *dx, *gf, *bx;
+    double *y, *Einv, *yhat, *gh, *dy, *tmp; // row data other lanes read (dy: soft rows only); tmp: staging
     double *ct, *st, *cc, *ctt, *stt, *cct;
     double *nu, *dnu, *crot;
     double *Aobs, *bobs, *xref;
@@ -410,56 +410,44 @@ __device__ double row_jdx(const Lay& L, const Sh& S, const Inst& in, int r) {
     { const int q = r - L.r_mu, w4 = 4 * L.nO, k = q / w4; return d[L.imu(k) + (q - k * w4)]; }
 }
 
-// ---------------------------------------------------------------- per-row barrier algebra
-struct RowLin { double Ds, Dp, Dn, rs, rp, rn, gs; bool hasL, hasU, eq; };
+// ---------------------------------------------------------------- lane-owned rows (registers)
+// Row r = lane + 64*j lives in slot j of its owner lane: bounds, slack, elastic pair, multipliers, the row value
+// and the per-iteration linearisation (inverse D's and residuals) never leave registers.  Only what OTHER lanes
+// need goes to LDS: y (gather / curvature), yhat, Einv, ghat (assembly, Riccati).
+template <int RPL>
+struct Rows {
+    double lo[RPL], up[RPL], s[RPL], p[RPL], n[RPL], y[RPL], zL[RPL], zU[RPL], zp[RPL], zn[RPL], g[RPL], dy[RPL];
+    double iDs[RPL], iDp[RPL], iDn[RPL], rs[RPL], rp[RPL], rn[RPL];
+};
 
-__device__ __forceinline__ RowLin row_lin(const Lay& L, const Sh& S, int r, double mu, double rho, double dw) {
-    RowLin q;
-    q.eq = row_iseq(L, r);
-    const double lo = S.Lb[r], up = S.Ub[r];
-    q.hasL = !q.eq && lo > -INFINITY;
-    q.hasU = !q.eq && up < INFINITY;
-    const double s = S.s[r], y = S.y[r];
-    double sig = 0.0, gs = 0.0;
-    if (q.hasL) { const double sl = s - lo; sig += S.zL[r] / sl; gs -= mu / sl; }
-    if (q.hasU) { const double su = up - s; sig += S.zU[r] / su; gs += mu / su; }
-    if (q.hasL && !q.hasU) gs += OBCA_KAPPA_D * mu;
-    if (q.hasU && !q.hasL) gs -= OBCA_KAPPA_D * mu;
-    q.gs = gs;
-    q.Ds = sig + dw;
-    q.Dp = S.zp[r] / S.p[r] + dw;
-    q.Dn = S.zn[r] / S.n[r] + dw;
-    q.rs = q.eq ? 0.0 : (-y + gs);
-    q.rp = rho - y - mu / S.p[r];
-    q.rn = rho + y - mu / S.n[r];
-    return q;
-}
-
-// ---------------------------------------------------------------- optimality error  (IPOPT eq. (5)/(6))
 struct Err { double E, dual, prim, comp; };
 
-__device__ Err ipm_errors(const Lay& L, const Sh& S, double mu, double rho, double rxmax, double crotmax,
+template <int RPL>
+__device__ Err ipm_errors(const Lay& L, const Rows<RPL>& W, double mu, double rho, double rxmax, double crotmax,
                           double nusum, int lane) {
     double dual = 0.0, prim = 0.0, comp = 0.0, ysum = 0.0, zsum = 0.0, nz = 0.0, nrow = 0.0;
-    for (int r = lane; r < L.R; r += 64) {
-        const double w = row_w(L, r);
-        const bool eq = row_iseq(L, r);
-        const double lo = S.Lb[r], up = S.Ub[r];
-        const bool hasL = !eq && lo > -INFINITY, hasU = !eq && up < INFINITY;
-        const double s = S.s[r], y = S.y[r], p = S.p[r], n = S.n[r];
-        const double zL = hasL ? S.zL[r] : 0.0, zU = hasU ? S.zU[r] : 0.0, zp = S.zp[r], zn = S.zn[r];
-        if (!eq) dual = dmaxabs(dual, -y - zL + zU);
-        dual = dmaxabs(dual, rho - y - zp);
-        dual = dmaxabs(dual, rho + y - zn);
-        prim = dmaxabs(prim, S.g[r] - (eq ? 0.0 : s) - p + n);
-        comp = dmaxabs(comp, p * zp - mu);
-        comp = dmaxabs(comp, n * zn - mu);
-        if (hasL) comp = dmaxabs(comp, (s - lo) * zL - mu);
-        if (hasU) comp = dmaxabs(comp, (up - s) * zU - mu);
-        ysum += w * fabs(y);
-        zsum += w * (zL + zU + zp + zn);
-        nz += w * ((hasL ? 1.0 : 0.0) + (hasU ? 1.0 : 0.0) + 2.0);
-        nrow += w;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        const int r = lane + 64 * j;
+        if (r < L.R) {
+            const double w = row_w(L, r);
+            const bool eq = row_iseq(L, r);
+            const bool hasL = !eq && W.lo[j] > -INFINITY, hasU = !eq && W.up[j] < INFINITY;
+            const double s = W.s[j], y = W.y[j], p = W.p[j], n = W.n[j];
+            const double zL = hasL ? W.zL[j] : 0.0, zU = hasU ? W.zU[j] : 0.0, zp = W.zp[j], zn = W.zn[j];
+            if (!eq) dual = dmaxabs(dual, -y - zL + zU);
+            dual = dmaxabs(dual, rho - y - zp);
+            dual = dmaxabs(dual, rho + y - zn);
+            prim = dmaxabs(prim, W.g[j] - (eq ? 0.0 : s) - p + n);
+            comp = dmaxabs(comp, p * zp - mu);
+            comp = dmaxabs(comp, n * zn - mu);
+            if (hasL) comp = dmaxabs(comp, (s - W.lo[j]) * zL - mu);
+            if (hasU) comp = dmaxabs(comp, (W.up[j] - s) * zU - mu);
+            ysum += w * fabs(y);
+            zsum += w * (zL + zU + zp + zn);
+            nz += w * ((hasL ? 1.0 : 0.0) + (hasU ? 1.0 : 0.0) + 2.0);
+            nrow += w;
+        }
     }
     dual = fmax(wave_max(dual), rxmax);
     prim = fmax(wave_max(prim), crotmax);
@@ -474,6 +462,37 @@ __device__ Err ipm_errors(const Lay& L, const Sh& S, double mu, double rho, doub
     e.dual = dual; e.prim = prim; e.comp = comp;
     e.E = fmax(fmax(dual / sd, prim), comp / sc);
     return e;
+}
+
+// linearisation of one row at the current iterate: inverse D's and residuals (IPOPT's Sigma + delta_w)
+struct Lin { double iDs, iDp, iDn, rs, rp, rn; };
+__device__ __forceinline__ Lin row_lin(double lo, double up, bool eq, double s, double p, double n, double y,
+                                       double zL, double zU, double zp, double zn, double mu, double rho, double dw) {
+    const bool hasL = !eq && lo > -INFINITY, hasU = !eq && up < INFINITY;
+    double sig = 0.0, gs = 0.0;
+    if (hasL) { const double isl = 1.0 / (s - lo); sig += zL * isl; gs -= mu * isl; }
+    if (hasU) { const double isu = 1.0 / (up - s); sig += zU * isu; gs += mu * isu; }
+    if (hasL && !hasU) gs += OBCA_KAPPA_D * mu;
+    if (hasU && !hasL) gs -= OBCA_KAPPA_D * mu;
+    const double ip = 1.0 / p, inn = 1.0 / n;
+    Lin q;
+    q.iDs = eq ? 0.0 : 1.0 / (sig + dw);
+    q.iDp = 1.0 / (zp * ip + dw);
+    q.iDn = 1.0 / (zn * inn + dw);
+    q.rs = eq ? 0.0 : (-y + gs);
+    q.rp = rho - y - mu * ip;
+    q.rn = rho + y - mu * inn;
+    return q;
+}
+
+// barrier terms of one row at (s, p, n): -mu*log(product of its distances) + linear damping; ONE log per row
+__device__ __forceinline__ double row_barrier(double lo, double up, bool eq, double s, double p, double n, double mu,
+                                              double rho) {
+    const bool hasL = !eq && lo > -INFINITY, hasU = !eq && up < INFINITY;
+    double prod = p * n, lin = rho * (p + n);
+    if (hasL) { prod *= (s - lo); if (!hasU) lin += OBCA_KAPPA_D * mu * (s - lo); }
+    if (hasU) { prod *= (up - s); if (!hasL) lin += OBCA_KAPPA_D * mu * (up - s); }
+    return lin - mu * dlog(prod);
 }
 
 // ---------------------------------------------------------------- stage-cost assembly (one lane per stage)
@@ -601,6 +620,9 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
 // wrong-sign pivot.
 __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw, int lane) {
     int bad = 0;
+#ifdef NO_LOCAL
+    return 0;
+#endif
     for (int pr = lane; pr < L.npair; pr += 64) {
         const int k = pr / L.nO, i = pr - k * L.nO;
         const int o0 = S.offm[i], m = S.offm[i + 1] - o0;
@@ -832,6 +854,9 @@ __device__ int soft_min(const Sh& S, const double* P, const double* q, const dou
 // ---------------------------------------------------------------- level 2: Riccati sweep + forward pass
 // Returns 1 on a wrong-sign pivot.  On success dx (poses, inputs, T) and dy of the soft rows are written.
 __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
+#ifdef NO_RICCATI
+    return 0;
+#endif
     const double* xv = S.x;
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
@@ -1028,8 +1053,8 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
 }  // namespace
 
 // ================================================================== the kernel
-extern "C" __global__ void __launch_bounds__(64)
-obca_ipm_kernel(ObcaLaunch A) {
+template <int RPL>
+__device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     const int inst = blockIdx.x;
@@ -1061,18 +1086,17 @@ obca_ipm_kernel(ObcaLaunch A) {
         double* p = smem;
         auto take = [&](int cnt) { double* q = p; p += (cnt + 1) & ~1; return q; };
         const int nmax = A.n_max, Rmax = A.R_max, np = L.npair, N1 = L.N + 1;
-        S.x = take(nmax); S.xt = take(nmax); S.dx = take(nmax); S.gf = take(nmax); S.rx = take(nmax); S.bx = take(nmax);
-        S.s = take(Rmax); S.p = take(Rmax); S.n = take(Rmax); S.y = take(Rmax); S.zL = take(Rmax); S.zU = take(Rmax);
-        S.zp = take(Rmax); S.zn = take(Rmax); S.g = take(Rmax); S.Einv = take(Rmax); S.yhat = take(Rmax);
-        S.gh = take(Rmax); S.dy = take(Rmax); S.Lb = take(Rmax); S.Ub = take(Rmax);
+        S.x = take(nmax); S.xt = take(nmax); S.dx = take(nmax); S.gf = take(nmax); S.bx = take(nmax);
+        S.y = take(Rmax); S.Einv = take(Rmax); S.yhat = take(Rmax); S.gh = take(Rmax); S.tmp = take(Rmax); S.dy = take(3 * N1 + 3);
         S.ct = take(N1); S.st = take(N1); S.cc = take(2 * np); S.ctt = take(N1); S.stt = take(N1); S.cct = take(2 * np);
         S.nu = take(2 * np); S.dnu = take(2 * np); S.crot = take(2 * np);
         S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
-        S.Lall = take(64 * N1); S.lall = take(8 * N1); S.Sloc = take(12 * np); S.Y = take(MW * 4 * np);
-        S.Pk = take(36 * N1); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
+        S.Lall = take(64 * N1); S.lall = take(8 * N1); S.Y = take(MW * 4 * np);
+        S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
         S.X = take(36); S.qt = take(6); S.FG = take(48); S.fv = take(6); S.Z = take(48); S.zv = take(6);
         S.Mall = take(64); S.mall = take(8); S.red = take(8);
         S.offm = reinterpret_cast<int*>(take(8));
+        S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
     }
     Inst& in = *reinterpret_cast<Inst*>(smem + A.inst_off);
     if (lane == 0) {
@@ -1143,32 +1167,47 @@ obca_ipm_kernel(ObcaLaunch A) {
     f = eval_objective<true>(L, S, in, S.x, sf, lane);
     double mu = OBCA_MU_INIT;
     // rows: bounds, slacks with bound push, elastic variables on their 1-d central path
+    Rows<RPL> W;
     {
         int bb = 0;
+        // heavy per-row code (the row-type switch) runs in rolled loops that stage through LDS; the unrolled
+        // register loops below only do arithmetic -- unrolling the switch RPL times exploded register pressure
         for (int r = lane; r < L.R; r += 64) {
             double lo, up;
             row_bounds(L, in, r, lo, up);
-            S.Lb[r] = lo; S.Ub[r] = up;
-            const bool eq = row_iseq(L, r);
-            const double g = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
-            double s = g;
-            const bool hasL = lo > -INFINITY, hasU = up < INFINITY;
-            if (eq) s = 0.0;
-            else if (hasL && hasU) {
-                if (!(lo < up)) bb = 1;
-                const double pL = fmin(OBCA_BOUND_PUSH * fmax(1.0, fabs(lo)), OBCA_BOUND_FRAC * (up - lo));
-                const double pU = fmin(OBCA_BOUND_PUSH * fmax(1.0, fabs(up)), OBCA_BOUND_FRAC * (up - lo));
-                s = fmin(fmax(s, lo + pL), up - pU);
-            } else if (hasL) s = fmax(s, lo + OBCA_BOUND_PUSH * fmax(1.0, fabs(lo)));
-            else if (hasU) s = fmin(s, up - OBCA_BOUND_PUSH * fmax(1.0, fabs(up)));
-            const double rr = g - s;
-            const double a = (mu - rho * rr) / (2.0 * rho);
-            const double en = a + sqrt(a * a + mu * rr / (2.0 * rho));
-            const double ep = rr + en;
-            S.g[r] = g; S.s[r] = s; S.p[r] = ep; S.n[r] = en;
-            S.zp[r] = mu / ep; S.zn[r] = mu / en; S.y[r] = rho - mu / ep;
-            S.zL[r] = (!eq && hasL) ? 1.0 : 0.0;
-            S.zU[r] = (!eq && hasU) ? 1.0 : 0.0;
+            S.Einv[r] = lo; S.gh[r] = up;
+            S.tmp[r] = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int r = lane + 64 * j;
+            W.lo[j] = 0.0; W.up[j] = 0.0; W.s[j] = 0.0; W.p[j] = 1.0; W.n[j] = 1.0; W.y[j] = 0.0;
+            W.zL[j] = 0.0; W.zU[j] = 0.0; W.zp[j] = 1.0; W.zn[j] = 1.0; W.g[j] = 0.0; W.dy[j] = 0.0;
+            W.iDs[j] = 0.0; W.iDp[j] = 1.0; W.iDn[j] = 1.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
+            if (r < L.R) {
+                const double lo = S.Einv[r], up = S.gh[r];
+                const bool eq = row_iseq(L, r);
+                const double g = S.tmp[r];
+                double s = g;
+                const bool hasL = lo > -INFINITY, hasU = up < INFINITY;
+                if (eq) s = 0.0;
+                else if (hasL && hasU) {
+                    if (!(lo < up)) bb = 1;
+                    const double pL = fmin(OBCA_BOUND_PUSH * fmax(1.0, fabs(lo)), OBCA_BOUND_FRAC * (up - lo));
+                    const double pU = fmin(OBCA_BOUND_PUSH * fmax(1.0, fabs(up)), OBCA_BOUND_FRAC * (up - lo));
+                    s = fmin(fmax(s, lo + pL), up - pU);
+                } else if (hasL) s = fmax(s, lo + OBCA_BOUND_PUSH * fmax(1.0, fabs(lo)));
+                else if (hasU) s = fmin(s, up - OBCA_BOUND_PUSH * fmax(1.0, fabs(up)));
+                const double rr = g - s;
+                const double a = (mu - rho * rr) / (2.0 * rho);
+                const double en = a + sqrt(a * a + mu * rr / (2.0 * rho));
+                const double ep = rr + en;
+                W.lo[j] = lo; W.up[j] = up; W.g[j] = g; W.s[j] = s; W.p[j] = ep; W.n[j] = en;
+                W.zp[j] = mu / ep; W.zn[j] = mu / en; W.y[j] = rho - mu / ep;
+                W.zL[j] = (!eq && hasL) ? 1.0 : 0.0;
+                W.zU[j] = (!eq && hasU) ? 1.0 : 0.0;
+                S.y[r] = W.y[j];
+            }
         }
         bad_bounds = wave_or(bb) != 0;
         for (int pr = lane; pr < L.npair; pr += 64) {
@@ -1195,20 +1234,24 @@ obca_ipm_kernel(ObcaLaunch A) {
     for (it = 0; it <= max_iter; ++it) {
         PROF(11)
         // ---- gradient of the Lagrangian and optimality error ------------------------------------------
-        gather_grad(L, S, in, S.y, S.rx, lane);
+        gather_grad(L, S, in, S.y, S.bx, lane);                    // bx doubles as scratch for grad_x L here
         double rxmax = 0.0, crotmax = 0.0, nusum = 0.0, th = 0.0, pnsum = 0.0;
-        for (int t = lane; t < L.n; t += 64) rxmax = dmaxabs(rxmax, S.rx[t]);
+        for (int t = lane; t < L.n; t += 64) rxmax = dmaxabs(rxmax, S.bx[t]);
         for (int t = lane; t < 2 * L.npair; t += 64) { crotmax = dmaxabs(crotmax, S.crot[t]); nusum += fabs(S.nu[t]); th += fabs(S.crot[t]); }
         double emax = 0.0;
-        for (int r = lane; r < L.R; r += 64) {
-            const double w = row_w(L, r);
-            th += w * fabs(S.g[r] - (row_iseq(L, r) ? 0.0 : S.s[r]) - S.p[r] + S.n[r]);
-            pnsum += w * (S.p[r] + S.n[r]);
-            emax = fmax(emax, S.p[r] + S.n[r]);
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int r = lane + 64 * j;
+            if (r < L.R) {
+                const double w = row_w(L, r);
+                th += w * fabs(W.g[j] - (row_iseq(L, r) ? 0.0 : W.s[j]) - W.p[j] + W.n[j]);
+                pnsum += w * (W.p[j] + W.n[j]);
+                emax = fmax(emax, W.p[j] + W.n[j]);
+            }
         }
         rxmax = wave_max(rxmax); crotmax = wave_max(crotmax); nusum = wave_sum(nusum); th = wave_sum(th);
         pnsum = wave_sum(pnsum); elastic_max = wave_max(emax);
-        const Err e0 = ipm_errors(L, S, 0.0, rho, rxmax, crotmax, nusum, lane);
+        const Err e0 = ipm_errors<RPL>(L, W, 0.0, rho, rxmax, crotmax, nusum, lane);
         E0 = e0.E;
         if (it == 0) {
             theta_max = OBCA_THETA_MAX_FACT * fmax(1.0, th);
@@ -1226,27 +1269,38 @@ obca_ipm_kernel(ObcaLaunch A) {
         {
             const double mu_floor = O.tol / (OBCA_KAPPA_EPS + 1.0);
             while (mu > mu_floor) {
-                const Err em = ipm_errors(L, S, mu, rho, rxmax, crotmax, nusum, lane);
+                const Err em = ipm_errors<RPL>(L, W, mu, rho, rxmax, crotmax, nusum, lane);
                 if (em.E > OBCA_KAPPA_EPS * mu) break;
-                mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, dpow(mu, OBCA_THETA_MU)));
+                mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, mu * sqrt(mu)));      // mu^theta_mu, theta_mu = 1.5
                 tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
                 f_valid = false;
             }
         }
         PROF(1)
         // ---- Newton step with inertia correction -----------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {       // unconditional writes end the live ranges of last iteration's step data,
+            W.dy[j] = 0.0; W.iDs[j] = 0.0; W.iDp[j] = 0.0; W.iDn[j] = 0.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
+        }                                      // so they do not occupy registers across the factorisation
         double delta_w = 0.0;
         bool first_try = true;
         int fail = 0;
         for (;;) {
-            for (int r = lane; r < L.R; r += 64) {
-                const RowLin q = row_lin(L, S, r, mu, rho, delta_w);
-                const double E = (q.eq ? 0.0 : 1.0 / q.Ds) + 1.0 / q.Dp + 1.0 / q.Dn;
-                const double rg = S.g[r] - (q.eq ? 0.0 : S.s[r]) - S.p[r] + S.n[r];
-                const double gh = rg + (q.eq ? 0.0 : q.rs / q.Ds) + q.rp / q.Dp - q.rn / q.Dn;
-                S.Einv[r] = 1.0 / E;
-                S.gh[r] = gh;
-                S.yhat[r] = row_soft(L, r) ? S.y[r] : (S.y[r] + gh / E);
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int r = lane + 64 * j;
+                if (r < L.R) {
+                    const bool eq = row_iseq(L, r);
+                    const double y = W.y[j];
+                    const Lin q = row_lin(W.lo[j], W.up[j], eq, W.s[j], W.p[j], W.n[j], y, W.zL[j], W.zU[j], W.zp[j],
+                                          W.zn[j], mu, rho, delta_w);
+                    const double rg = W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j];
+                    const double gh = rg + q.rs * q.iDs + q.rp * q.iDp - q.rn * q.iDn;
+                    const double Ei = 1.0 / (q.iDs + q.iDp + q.iDn);
+                    S.Einv[r] = Ei;
+                    S.gh[r] = gh;
+                    S.yhat[r] = row_soft(L, r) ? y : (y + gh * Ei);
+                }
             }
             SYNC();
             gather_grad(L, S, in, S.yhat, S.bx, lane);
@@ -1271,41 +1325,48 @@ obca_ipm_kernel(ObcaLaunch A) {
         if (delta_w > 0.0) delta_w_last = delta_w;
         // ---- row steps, step lengths, directional derivative -----------------------------------------------
         double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0;
-        for (int r = lane; r < L.R; r += 64) {
-            const RowLin q = row_lin(L, S, r, mu, rho, delta_w);
-            double dy;
-            if (row_soft(L, r)) dy = S.dy[r];
-            else { dy = (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r]; S.dy[r] = dy; }
-            const double w = row_w(L, r);
-            const double ds = q.eq ? 0.0 : (dy - q.rs) / q.Ds;
-            const double dp = (dy - q.rp) / q.Dp;
-            const double dn = (-dy - q.rn) / q.Dn;
-            const double s = S.s[r], p = S.p[r], n = S.n[r];
-            const double lo = S.Lb[r], up = S.Ub[r];
-            if (q.hasL) {
-                const double sl = s - lo, zL = S.zL[r];
-                if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
-                const double dz = (mu - zL * ds) / sl - zL;
-                if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
-                phi -= w * mu * dlog(sl);
-                if (!q.hasU) phi += w * OBCA_KAPPA_D * mu * sl;
+        for (int r = lane; r < L.R; r += 64)
+            S.tmp[r] = row_soft(L, r) ? S.dy[r] : (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r];
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int r = lane + 64 * j;
+            if (r < L.R) {
+                const bool eq = row_iseq(L, r);
+                const bool hasL = !eq && W.lo[j] > -INFINITY, hasU = !eq && W.up[j] < INFINITY;
+                const double dy = S.tmp[r];
+                W.dy[j] = dy;
+                {   // cached for the line search and the update (not kept live across the factorisation)
+                    const Lin q = row_lin(W.lo[j], W.up[j], eq, W.s[j], W.p[j], W.n[j], W.y[j], W.zL[j], W.zU[j], W.zp[j],
+                                          W.zn[j], mu, rho, delta_w);
+                    W.iDs[j] = q.iDs; W.iDp[j] = q.iDp; W.iDn[j] = q.iDn; W.rs[j] = q.rs; W.rp[j] = q.rp; W.rn[j] = q.rn;
+                }
+                const double w = row_w(L, r);
+                const double ds = (dy - W.rs[j]) * W.iDs[j];
+                const double dp = (dy - W.rp[j]) * W.iDp[j];
+                const double dn = (-dy - W.rn[j]) * W.iDn[j];
+                const double s = W.s[j], p = W.p[j], n = W.n[j];
+                double gs = eq ? 0.0 : W.rs[j] + W.y[j];
+                if (hasL) {
+                    const double sl = s - W.lo[j], zL = W.zL[j];
+                    if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
+                    const double dz = (mu - zL * ds) / sl - zL;
+                    if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
+                }
+                if (hasU) {
+                    const double su = W.up[j] - s, zU = W.zU[j];
+                    if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
+                    const double dz = (mu + zU * ds) / su - zU;
+                    if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
+                }
+                if (dp < 0.0) a_max = fmin(a_max, -tau * p / dp);
+                if (dn < 0.0) a_max = fmin(a_max, -tau * n / dn);
+                const double zp = W.zp[j], zn = W.zn[j];
+                const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
+                if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
+                if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
+                phi += w * row_barrier(W.lo[j], W.up[j], eq, s, p, n, mu, rho);
+                dphi += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
             }
-            if (q.hasU) {
-                const double su = up - s, zU = S.zU[r];
-                if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
-                const double dz = (mu + zU * ds) / su - zU;
-                if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
-                phi -= w * mu * dlog(su);
-                if (!q.hasL) phi += w * OBCA_KAPPA_D * mu * su;
-            }
-            if (dp < 0.0) a_max = fmin(a_max, -tau * p / dp);
-            if (dn < 0.0) a_max = fmin(a_max, -tau * n / dn);
-            const double zp = S.zp[r], zn = S.zn[r];
-            const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
-            if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
-            if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
-            phi += w * (rho * (p + n) - mu * (dlog(p) + dlog(n)));
-            dphi += w * (q.gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
         }
         for (int t = lane; t < L.n; t += 64) dphi += S.gf[t] * S.dx[t];
         a_max = wave_min(a_max); a_z = wave_min(a_z); dphi = wave_sum(dphi); phi = wave_sum(phi) + f;
@@ -1325,18 +1386,20 @@ obca_ipm_kernel(ObcaLaunch A) {
             eval_geom(L, S, S.xt, S.ctt, S.stt, S.cct, lane);
             f_t = eval_objective<false>(L, S, in, S.xt, sf, lane);
             double th_t = 0.0, phi_t = 0.0;
-            for (int r = lane; r < L.R; r += 64) {
-                const RowLin q = row_lin(L, S, r, mu, rho, delta_w);
-                const double dy = S.dy[r];
-                const double w = row_w(L, r);
-                const double st = q.eq ? 0.0 : S.s[r] + alpha * (dy - q.rs) / q.Ds;
-                const double pt = S.p[r] + alpha * (dy - q.rp) / q.Dp;
-                const double nt = S.n[r] + alpha * (-dy - q.rn) / q.Dn;
-                const double gt = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
-                th_t += w * fabs(gt - st - pt + nt);
-                phi_t += w * (rho * (pt + nt) - mu * (dlog(pt) + dlog(nt)));
-                if (q.hasL) { const double sl = st - S.Lb[r]; phi_t -= w * mu * dlog(sl); if (!q.hasU) phi_t += w * OBCA_KAPPA_D * mu * sl; }
-                if (q.hasU) { const double su = S.Ub[r] - st; phi_t -= w * mu * dlog(su); if (!q.hasL) phi_t += w * OBCA_KAPPA_D * mu * su; }
+            for (int r = lane; r < L.R; r += 64) S.tmp[r] = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int r = lane + 64 * j;
+                if (r < L.R) {
+                    const bool eq = row_iseq(L, r);
+                    const double dy = W.dy[j], w = row_w(L, r);
+                    const double st = eq ? 0.0 : W.s[j] + alpha * (dy - W.rs[j]) * W.iDs[j];
+                    const double pt = W.p[j] + alpha * (dy - W.rp[j]) * W.iDp[j];
+                    const double nt = W.n[j] + alpha * (-dy - W.rn[j]) * W.iDn[j];
+                    const double gt = S.tmp[r];
+                    th_t += w * fabs(gt - st - pt + nt);
+                    phi_t += w * row_barrier(W.lo[j], W.up[j], eq, st, pt, nt, mu, rho);
+                }
             }
             for (int pr = lane; pr < L.npair; pr += 64) {
                 double e1, e2;
@@ -1373,32 +1436,38 @@ obca_ipm_kernel(ObcaLaunch A) {
             if (lane == slot) { f_valid = true; f_th = tn; f_phi = pn; }
         }
         // ---- accept ------------------------------------------------------------------------------------------
-        for (int r = lane; r < L.R; r += 64) {
-            const RowLin q = row_lin(L, S, r, mu, rho, delta_w);
-            const double dy = S.dy[r];
-            const double ds = q.eq ? 0.0 : (dy - q.rs) / q.Ds;
-            const double dp = (dy - q.rp) / q.Dp;
-            const double dn = (-dy - q.rn) / q.Dn;
-            const double lo = S.Lb[r], up = S.Ub[r];
-            const double s_old = S.s[r], p_old = S.p[r], n_old = S.n[r];
-            const double s = q.eq ? 0.0 : s_old + alpha * ds, p = p_old + alpha * dp, n = n_old + alpha * dn;
-            const double ks = OBCA_KAPPA_SIGMA;
-            if (q.hasL) {
-                const double zL = S.zL[r] + a_z * ((mu - S.zL[r] * ds) / (s_old - lo) - S.zL[r]);
-                const double sl = s - lo;
-                S.zL[r] = fmax(fmin(zL, ks * mu / sl), mu / (ks * sl));
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int r = lane + 64 * j;
+            if (r < L.R) {
+                const bool eq = row_iseq(L, r);
+                const bool hasL = !eq && W.lo[j] > -INFINITY, hasU = !eq && W.up[j] < INFINITY;
+                const double dy = W.dy[j];
+                const double ds = (dy - W.rs[j]) * W.iDs[j];
+                const double dp = (dy - W.rp[j]) * W.iDp[j];
+                const double dn = (-dy - W.rn[j]) * W.iDn[j];
+                const double lo = W.lo[j], up = W.up[j];
+                const double s_old = W.s[j], p_old = W.p[j], n_old = W.n[j];
+                const double s = eq ? 0.0 : s_old + alpha * ds, p = p_old + alpha * dp, n = n_old + alpha * dn;
+                const double ks = OBCA_KAPPA_SIGMA;
+                if (hasL) {
+                    const double zL = W.zL[j] + a_z * ((mu - W.zL[j] * ds) / (s_old - lo) - W.zL[j]);
+                    const double sl = s - lo;
+                    W.zL[j] = fmax(fmin(zL, ks * mu / sl), mu / (ks * sl));
+                }
+                if (hasU) {
+                    const double zU = W.zU[j] + a_z * ((mu + W.zU[j] * ds) / (up - s_old) - W.zU[j]);
+                    const double su = up - s;
+                    W.zU[j] = fmax(fmin(zU, ks * mu / su), mu / (ks * su));
+                }
+                const double zp = W.zp[j] + a_z * ((mu - W.zp[j] * dp) / p_old - W.zp[j]);
+                const double zn = W.zn[j] + a_z * ((mu - W.zn[j] * dn) / n_old - W.zn[j]);
+                W.zp[j] = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
+                W.zn[j] = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
+                W.s[j] = s; W.p[j] = p; W.n[j] = n;
+                W.y[j] += alpha * dy;
+                S.y[r] = W.y[j];
             }
-            if (q.hasU) {
-                const double zU = S.zU[r] + a_z * ((mu + S.zU[r] * ds) / (up - s_old) - S.zU[r]);
-                const double su = up - s;
-                S.zU[r] = fmax(fmin(zU, ks * mu / su), mu / (ks * su));
-            }
-            const double zp = S.zp[r] + a_z * ((mu - S.zp[r] * dp) / p_old - S.zp[r]);
-            const double zn = S.zn[r] + a_z * ((mu - S.zn[r] * dn) / n_old - S.zn[r]);
-            S.zp[r] = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
-            S.zn[r] = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
-            S.s[r] = s; S.p[r] = p; S.n[r] = n;
-            S.y[r] += alpha * dy;
         }
         for (int t = lane; t < 2 * L.npair; t += 64) S.nu[t] += alpha * S.dnu[t];
         for (int t = lane; t < L.n; t += 64) S.x[t] = S.xt[t];
@@ -1409,7 +1478,12 @@ obca_ipm_kernel(ObcaLaunch A) {
         // ---- re-evaluate at the new iterate ------------------------------------------------------------------
         eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
         f = eval_objective<true>(L, S, in, S.x, sf, lane);
-        for (int r = lane; r < L.R; r += 64) S.g[r] = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
+        for (int r = lane; r < L.R; r += 64) S.tmp[r] = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int r = lane + 64 * j;
+            if (r < L.R) W.g[j] = S.tmp[r];
+        }
         for (int pr = lane; pr < L.npair; pr += 64) {
             double e1, e2;
             rot_value(L, S.x, S.ct, S.st, S.cc, pr, e1, e2);
@@ -1443,3 +1517,7 @@ obca_ipm_kernel(ObcaLaunch A) {
         }
     }
 }
+
+// rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A) { obca_ipm_body<4>(A); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A) { obca_ipm_body<6>(A); }
