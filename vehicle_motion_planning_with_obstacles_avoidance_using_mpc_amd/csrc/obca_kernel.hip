@@ -799,60 +799,52 @@ __device__ __forceinline__ int inv3_ipe(const double* P, int ld, const double* E
     return bad;
 }
 
-// soft-min of V(p', o) = 1/2 [p';o]'P[p';o] + q'[p';o] against 1/2 (p'-phat)' E^-1 (p'-phat); writes X, qt
-__device__ int soft_min(const Sh& S, const double* P, const double* q, const double* E, double* MiOut, int lane) {
-    double Mr[9];
-    const int bad = inv3_ipe(P, 6, E, Mr);
+// soft-min of V(p', o) = 1/2 [p';o]'P[p';o] + q'[p';o] against 1/2 (p'-phat)' E^-1 (p'-phat), entirely in
+// registers and redundantly in every lane (no LDS round trip):  X = P~ (symmetric 6x6), qt = q~, Mi = (I+Ppp E)^-1
+__device__ __forceinline__ int soft_min_regs(const double* Pl, const double* ql, const double E[3], double X[36],
+                                             double qt[6], double Mi[9]) {
+    double P[36], q[6];
 #pragma unroll
-    for (int c = 0; c < 9; ++c)
-        if (lane == c) MiOut[c] = Mr[c];           // static register index; rows are re-read from LDS below
-    SYNC();
-    const double* Mi = MiOut;
-    if (lane < 36) {
-        const int a = lane / 6, b = lane - 6 * a;
-        double v;
-        if (a < 3) {                               // M [Ppp Ppo]
-            v = Mi[3 * a] * P[b] + Mi[3 * a + 1] * P[6 + b] + Mi[3 * a + 2] * P[12 + b];
-        } else if (b < 3) {                        // symmetric copy of (M Ppo)'
-            v = Mi[3 * b] * P[a] + Mi[3 * b + 1] * P[6 + a] + Mi[3 * b + 2] * P[12 + a];
-        } else {                                   // Poo - Pop E M Ppo
-            v = P[6 * a + b];
+    for (int i = 0; i < 36; ++i) P[i] = Pl[i];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double emp = E[c] * (Mi[3 * c] * P[b] + Mi[3 * c + 1] * P[6 + b] + Mi[3 * c + 2] * P[12 + b]);
-                v -= P[6 * a + c] * emp;
-            }
+    for (int i = 0; i < 6; ++i) q[i] = ql[i];
+    const int bad = inv3_ipe(P, 6, E, Mi);
+    double MP[18];                              // Mi [Ppp Ppo]  (3 x 6)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) MP[6 * a + c] = Mi[3 * a] * P[c] + Mi[3 * a + 1] * P[6 + c] + Mi[3 * a + 2] * P[12 + c];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[6 * a + c] = 0.5 * (MP[6 * a + c] + MP[6 * c + a]);
+#pragma unroll
+        for (int c = 3; c < 6; ++c) { X[6 * a + c] = MP[6 * a + c]; X[6 * c + a] = MP[6 * a + c]; }
+    }
+#pragma unroll
+    for (int a = 3; a < 6; ++a)
+#pragma unroll
+        for (int c = 3; c < 6; ++c) {           // Poo - Pop E (M Ppo)
+            double v = P[6 * a + c];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) v -= P[6 * a + e] * E[e] * MP[6 * e + c];
+            X[6 * a + c] = v;
         }
-        S.X[lane] = v;
-    } else if (lane < 42) {
-        const int a = lane - 36;
-        double v;
-        if (a < 3) v = Mi[3 * a] * q[0] + Mi[3 * a + 1] * q[1] + Mi[3 * a + 2] * q[2];
-        else {
-            v = q[a];
+    double Mq[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                v -= P[6 * a + c] * E[c] * (Mi[3 * c] * q[0] + Mi[3 * c + 1] * q[1] + Mi[3 * c + 2] * q[2]);
-        }
-        S.qt[a] = v;
-    }
-    SYNC();
-    double vsym = 0.0;
-    if (lane < 9) {                                // symmetrise the pp block
-        const int a = lane / 3, b = lane - 3 * a;
-        vsym = 0.5 * (S.X[6 * a + b] + S.X[6 * b + a]);
-    }
-    SYNC();
-    if (lane < 9) {
-        const int a = lane / 3, b = lane - 3 * a;
-        S.X[6 * a + b] = vsym;
-    }
-    SYNC();
+    for (int a = 0; a < 3; ++a) Mq[a] = Mi[3 * a] * q[0] + Mi[3 * a + 1] * q[1] + Mi[3 * a + 2] * q[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) qt[a] = Mq[a];
+#pragma unroll
+    for (int a = 3; a < 6; ++a) qt[a] = q[a] - (P[6 * a] * E[0] * Mq[0] + P[6 * a + 1] * E[1] * Mq[1] + P[6 * a + 2] * E[2] * Mq[2]);
     return bad;
 }
 
 // ---------------------------------------------------------------- level 2: Riccati sweep + forward pass
-// Returns 1 on a wrong-sign pivot.  On success dx (poses, inputs, T) and dy of the soft rows are written.
+// Two LDS round trips per stage: (A) every lane rebuilds P~ in registers and produces ONE entry of the 8x8
+// stage matrix Mall = Lall + [F G]' P~ [F G]; (B) every lane inverts the 2x2 input block and produces one entry
+// of P_k / q_k / K.  Returns 1 on a wrong-sign pivot; on success dx (poses, inputs, T) and the multiplier steps
+// of the soft rows are written.
 __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
 #ifdef NO_RICCATI
     return 0;
@@ -861,122 +853,108 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
     int bad = 0;
-    // terminal value function
-    double* PN = S.Pk + 36 * L.N;
-    double* qN = S.qk + 6 * L.N;
-    if (lane < 36) {
-        const int a = lane / 6, b = lane - 6 * a;
-        PN[lane] = (a < 3 && b < 3) ? S.Lall[64 * L.N + 8 * a + b] : 0.0;
-    } else if (lane < 42) {
-        const int a = lane - 36;
-        qN[a] = (a < 3) ? S.lall[8 * L.N + a] : 0.0;
+    // [F G] of every stage (6 x 8 each) and the terminal value function, one phase
+    for (int t = lane; t < 48 * L.N; t += 64) {
+        const int k = t / 48, e = t - 48 * k, a = e >> 3, b = e & 7;
+        const double cs = S.ct[k], sn = S.st[k];
+        const double* u = xv + L.iu(k);
+        double v = 0.0;
+        if (a < 3) {
+            if (b < 3) v = (a == b) ? 1.0 : 0.0;
+            if (b == 2) { if (a == 0) v = -h * u[0] * sn; else if (a == 1) v = h * u[0] * cs; }
+            if (b == 5 && L.free_T) v = in.Ts * ((a == 0) ? u[0] * cs : (a == 1) ? u[0] * sn : u[1]);
+            if (b == 6) v = (a == 0) ? h * cs : (a == 1) ? h * sn : 0.0;
+            if (b == 7) v = (a == 2) ? h : 0.0;
+        } else if (a < 5) {
+            v = (b == 6 + (a - 3)) ? 1.0 : 0.0;
+        } else {
+            v = (b == 5) ? 1.0 : 0.0;
+        }
+        S.FG[t] = v;
+    }
+    {
+        double* PN = S.Pk + 36 * L.N;
+        double* qN = S.qk + 6 * L.N;
+        if (lane < 36) {
+            const int a = lane / 6, b = lane - 6 * a;
+            PN[lane] = (a < 3 && b < 3) ? S.Lall[64 * L.N + 8 * a + b] : 0.0;
+        } else if (lane < 42) {
+            const int a = lane - 36;
+            qN[a] = (a < 3) ? S.lall[8 * L.N + a] : 0.0;
+        }
     }
     SYNC();
     for (int k = L.N - 1; k >= 0; --k) {
-        const double* P1 = S.Pk + 36 * (k + 1);
-        const double* q1 = S.qk + 6 * (k + 1);
-        double E[3], gh[3];
+        // ---- phase A ----------------------------------------------------------------------------------
+        double E[3], gh[3], X[36], qt[6], Mi[9];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { E[j] = 1.0 / S.Einv[L.r_dyn + 3 * k + j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
-        bad |= soft_min(S, P1, q1, E, S.Mik + 9 * k, lane);
-        // [F G] (6 x 8) and f
-        if (lane < 48) {
-            const int a = lane / 8, b = lane - 8 * a;
-            const double cs = S.ct[k], sn = S.st[k];
-            const double* u = xv + L.iu(k);
-            double v = 0.0;
-            if (a < 3) {
-                if (b < 3) v = (a == b) ? 1.0 : 0.0;
-                if (b == 2) { if (a == 0) v = -h * u[0] * sn; else if (a == 1) v = h * u[0] * cs; }
-                if (b == 5 && L.free_T) v = in.Ts * ((a == 0) ? u[0] * cs : (a == 1) ? u[0] * sn : u[1]);
-                if (b == 6) v = (a == 0) ? h * cs : (a == 1) ? h * sn : 0.0;
-                if (b == 7) v = (a == 2) ? h : 0.0;
-            } else if (a < 5) {
-                v = (b == 6 + (a - 3)) ? 1.0 : 0.0;
-            } else {
-                v = (b == 5) ? 1.0 : 0.0;
-            }
-            S.FG[lane] = v;
-        } else if (lane < 54) {
-            const int a = lane - 48;
-            S.fv[a] = (a < 3) ? -gh[a] : 0.0;
-        }
-        SYNC();
-        // Z = X [F G],  zv = X f + qt
-        if (lane < 48) {
-            const int a = lane / 8, b = lane - 8 * a;
-            double v = 0.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) v += S.X[6 * a + c] * S.FG[8 * c + b];
-            S.Z[lane] = v;
-        } else if (lane < 54) {
-            const int a = lane - 48;
-            double v = S.qt[a];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) v += S.X[6 * a + c] * S.fv[c];
-            S.zv[a] = v;
-        }
-        SYNC();
-        // Mall = Lall + [F G]' Z,  mall = lall + [F G]' zv
+        bad |= soft_min_regs(S.Pk + 36 * (k + 1), S.qk + 6 * (k + 1), E, X, qt, Mi);
         {
             const int a = lane >> 3, b = lane & 7;
+            const double* FGk = S.FG + 48 * k;
+            double fa[6], fb[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { fa[c] = FGk[8 * c + a]; fb[c] = FGk[8 * c + b]; }
             double v = S.Lall[64 * k + lane];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) v += S.FG[8 * c + a] * S.Z[8 * c + b];
-            S.Mall[lane] = v;
-            if (lane < 8) {
-                double w = S.lall[8 * k + lane];
+            for (int c = 0; c < 6; ++c) {
+                double z = 0.0;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) w += S.FG[8 * c + lane] * S.zv[c];
-                S.mall[lane] = w;
+                for (int d = 0; d < 6; ++d) z += X[6 * c + d] * fb[d];
+                v += fa[c] * z;
             }
+            S.Mall[lane] = v;
+            if (b == 0) {               // gradient: lall + [F G]'(X f + qt), f = (-ghat, 0, 0, 0)
+                double w = S.lall[8 * k + a];
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    w += fa[c] * (qt[c] - (X[6 * c] * gh[0] + X[6 * c + 1] * gh[1] + X[6 * c + 2] * gh[2]));
+                S.mall[a] = w;
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+                if (lane == c) S.Mik[9 * k + c] = Mi[c];
         }
         SYNC();
-        // input block: 2x2 Cholesky-type pivots must be positive
+        // ---- phase B ----------------------------------------------------------------------------------
         const double m00 = S.Mall[8 * 6 + 6], m01 = 0.5 * (S.Mall[8 * 6 + 7] + S.Mall[8 * 7 + 6]), m11 = S.Mall[8 * 7 + 7];
         const double d1 = m11 - m01 * m01 / m00;
         if (!(m00 > 0.0) || !(d1 > 0.0)) bad = 1;
         const double idet = 1.0 / (m00 * d1);
         const double i00 = m11 * idet, i01 = -m01 * idet, i11 = m00 * idet;
-        if (lane < 12) {                                   // K = -Muu^-1 Mxu'
-            const int uu = lane / 6, a = lane - 6 * uu;
-            const double x0 = 0.5 * (S.Mall[8 * a + 6] + S.Mall[8 * 6 + a]), x1 = 0.5 * (S.Mall[8 * a + 7] + S.Mall[8 * 7 + a]);
-            S.Kk[12 * k + lane] = -((uu == 0) ? (i00 * x0 + i01 * x1) : (i01 * x0 + i11 * x1));
-        } else if (lane < 14) {
-            const int uu = lane - 12;
-            S.kapk[2 * k + uu] = -((uu == 0) ? (i00 * S.mall[6] + i01 * S.mall[7]) : (i01 * S.mall[6] + i11 * S.mall[7]));
-        }
-        SYNC();
-        if (lane < 36) {                                   // P_k = Mxx + Mxu K (symmetrised)
-            const int a = lane / 6, b = lane - 6 * a;
+        if (lane < 42) {
+            const int a = (lane < 36) ? lane / 6 : lane - 36, b = (lane < 36) ? lane - 6 * (lane / 6) : 0;
             const double xa0 = 0.5 * (S.Mall[8 * a + 6] + S.Mall[8 * 6 + a]), xa1 = 0.5 * (S.Mall[8 * a + 7] + S.Mall[8 * 7 + a]);
-            const double xb0 = 0.5 * (S.Mall[8 * b + 6] + S.Mall[8 * 6 + b]), xb1 = 0.5 * (S.Mall[8 * b + 7] + S.Mall[8 * 7 + b]);
-            const double v1 = S.Mall[8 * a + b] + xa0 * S.Kk[12 * k + b] + xa1 * S.Kk[12 * k + 6 + b];
-            const double v2 = S.Mall[8 * b + a] + xb0 * S.Kk[12 * k + a] + xb1 * S.Kk[12 * k + 6 + a];
-            S.Pk[36 * k + lane] = 0.5 * (v1 + v2);
-        } else if (lane < 42) {
-            const int a = lane - 36;
-            const double xa0 = 0.5 * (S.Mall[8 * a + 6] + S.Mall[8 * 6 + a]), xa1 = 0.5 * (S.Mall[8 * a + 7] + S.Mall[8 * 7 + a]);
-            S.qk[6 * k + a] = S.mall[a] + xa0 * S.kapk[2 * k] + xa1 * S.kapk[2 * k + 1];
+            if (lane < 36) {            // P_k = Mxx - Mxu Muu^-1 Mxu'
+                const double xb0 = 0.5 * (S.Mall[8 * b + 6] + S.Mall[8 * 6 + b]), xb1 = 0.5 * (S.Mall[8 * b + 7] + S.Mall[8 * 7 + b]);
+                const double kb0 = -(i00 * xb0 + i01 * xb1), kb1 = -(i01 * xb0 + i11 * xb1);
+                S.Pk[36 * k + lane] = 0.5 * (S.Mall[8 * a + b] + S.Mall[8 * b + a]) + xa0 * kb0 + xa1 * kb1;
+                if (a == 0) { S.Kk[12 * k + b] = kb0; S.Kk[12 * k + 6 + b] = kb1; }      // K = -Muu^-1 Mxu'
+            } else {
+                const double k0 = -(i00 * S.mall[6] + i01 * S.mall[7]), k1 = -(i01 * S.mall[6] + i11 * S.mall[7]);
+                S.qk[6 * k + a] = S.mall[a] + xa0 * k0 + xa1 * k1;
+                if (a == 0) { S.kapk[2 * k] = k0; S.kapk[2 * k + 1] = k1; }
+            }
         }
         SYNC();
     }
     // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
-    double E0[3], g0[3];
+    double E0[3], g0[3], X[36], qt[6], Mi0[9];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { E0[j] = 1.0 / S.Einv[L.r_init + j]; g0[j] = S.gh[L.r_init + j]; }
-    bad |= soft_min(S, S.Pk, S.qk, E0, S.Mik + 9 * L.N, lane);
-    if (L.free_T && !(S.X[35] > 0.0)) bad = 1;
+    bad |= soft_min_regs(S.Pk, S.qk, E0, X, qt, Mi0);
+    if (L.free_T && !(X[35] > 0.0)) bad = 1;
     bad = wave_or(bad);
     if (bad) return 1;
     // ---- forward pass: every lane carries the (tiny) state redundantly, lane 0 stores
     double dT = 0.0;
-    if (L.free_T) dT = -(S.qt[5] - (S.X[30] * g0[0] + S.X[31] * g0[1] + S.X[32] * g0[2])) / S.X[35];
+    if (L.free_T) dT = -(qt[5] - (X[30] * g0[0] + X[31] * g0[1] + X[32] * g0[2])) / X[35];
     double dp[3], up[2] = {0.0, 0.0};
     {
         const double* P0 = S.Pk;
         const double* q0 = S.qk;
-        const double* Mi = S.Mik + 9 * L.N;
+        const double* Mi = Mi0;
         double t[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) t[a] = -g0[a] - E0[a] * (P0[6 * a + 5] * dT + q0[a]);
@@ -1093,7 +1071,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
         S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
         S.Lall = take(64 * N1); S.lall = take(8 * N1); S.Y = take(MW * 4 * np);
         S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
-        S.X = take(36); S.qt = take(6); S.FG = take(48); S.fv = take(6); S.Z = take(48); S.zv = take(6);
+        S.X = take(36); S.qt = take(6); S.FG = take(48 * N1); S.fv = take(6); S.Z = take(48); S.zv = take(6);
         S.Mall = take(64); S.mall = take(8); S.red = take(8);
         S.offm = reinterpret_cast<int*>(take(8));
         S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
