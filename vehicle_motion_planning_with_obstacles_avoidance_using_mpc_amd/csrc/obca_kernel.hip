@@ -40,27 +40,34 @@ __device__ __noinline__ double dlog(double x) { return log(x); }
 __device__ __noinline__ double dpow(double x, double y) { return exp(y * log(x)); }
 __device__ __noinline__ void dsincos(double x, double* s, double* c) { sincos(x, s, c); }
 
-// ---------------------------------------------------------------- wave reductions (64 lanes, butterfly)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+// DPP within each row of 16 lanes (no LDS crossbar: __shfl_xor lowers to ds_bpermute, ~12 dependent LDS
+// round trips per fp64 reduction), then the four row results are read with v_readlane and combined as
+// scalars, so the result is uniform by construction.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+__device__ __forceinline__ double lane_read(double v, int l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_or(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-    return v;
-}
+#define OBCA_ROW_REDUCE(OP)                                                          \
+    v = OP(v, dpp_move<0xB1>(v));  /* quad_perm [1,0,3,2] */                         \
+    v = OP(v, dpp_move<0x4E>(v));  /* quad_perm [2,3,0,1] */                         \
+    v = OP(v, dpp_move<0x141>(v)); /* row_half_mirror */                             \
+    v = OP(v, dpp_move<0x140>(v)); /* row_mirror: every lane holds its row's result */ \
+    const double r0 = lane_read(v, 0), r1 = lane_read(v, 16), r2 = lane_read(v, 32), r3 = lane_read(v, 48);
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double wave_sum(double v) { OBCA_ROW_REDUCE(op_add) return (r0 + r1) + (r2 + r3); }
+__device__ __forceinline__ double wave_max(double v) { OBCA_ROW_REDUCE(fmax) return fmax(fmax(r0, r1), fmax(r2, r3)); }
+__device__ __forceinline__ double wave_min(double v) { OBCA_ROW_REDUCE(fmin) return fmin(fmin(r0, r1), fmin(r2, r3)); }
+__device__ __forceinline__ int wave_or(int v) { return __any(v) ? 1 : 0; }
 
 // ---------------------------------------------------------------- instance layout
 struct Lay {
@@ -623,7 +630,11 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
 #ifdef NO_LOCAL
     return 0;
 #endif
-    for (int pr = lane; pr < L.npair; pr += 64) {
+    // TWO lanes per pair: both factor the block (registers), each solves two of the four right-hand sides
+    // [G_x G_y | G_theta rloc] and produces the matching columns of Y and of the Schur complement G'Y.
+    for (int w = lane; w < 2 * L.npair; w += 64) {
+        const int pr = w >> 1;
+        const bool hi = (w & 1) != 0;
         const int k = pr / L.nO, i = pr - k * L.nO;
         const int o0 = S.offm[i], m = S.offm[i + 1] - o0;
         const double cs = S.ct[k], sn = S.st[k];
@@ -633,9 +644,8 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
         const double yn = S.y[L.r_norm + pr], En = S.Einv[L.r_norm + pr];
         const double yd = S.y[L.r_dist + pr], Ed = S.Einv[L.r_dist + pr];
         const double nu1 = S.nu[2 * pr], nu2 = S.nu[2 * pr + 1];
-        // Packed lower-triangular K (MW*(MW+1)/2 registers); Yv starts as [G | rloc] and is solved in place.
         double a0[OBCA_MAX_EDGES], a1[OBCA_MAX_EDGES], gn[OBCA_MAX_EDGES], gd[NW];
-        double K[MW * (MW + 1) / 2], Yv[MW][4];
+        double K[MW * (MW + 1) / 2], Yv[MW][2], Gm[MW][3];
 #define KP(a, b) K[((a) * ((a) + 1)) / 2 + (b)]
         const double dth = -sn * c0 + cs * c1;          // d(dist)/d(theta) / off  and  d(e1)/d(theta)
 #pragma unroll
@@ -659,15 +669,16 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
                     if (a < OBCA_MAX_EDGES) v += En * gn[a] * gn[b] + yn * 2.0 * (a0[a] * a0[b] + a1[a] * a1[b]);
                     KP(a, b) = v;
                 }
+        double rl[MW];
 #pragma unroll
         for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
             const bool on = j < m;
             KP(j, j) += on ? (dw + S.Einv[L.r_lam + k * L.M + o0 + j]) : 1.0;   // padded slots: identity
-            Yv[j][3] = on ? -S.bx[L.il(k) + o0 + j] : 0.0;
+            rl[j] = on ? -S.bx[L.il(k) + o0 + j] : 0.0;
             // coupling to the pose: columns (x, y, theta)
-            Yv[j][0] = Ed * gd[j] * c0 + yd * a0[j];
-            Yv[j][1] = Ed * gd[j] * c1 + yd * a1[j];
-            Yv[j][2] = Ed * gd[j] * in.off * dth + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
+            Gm[j][0] = Ed * gd[j] * c0 + yd * a0[j];
+            Gm[j][1] = Ed * gd[j] * c1 + yd * a1[j];
+            Gm[j][2] = Ed * gd[j] * in.off * dth + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
                        nu1 * (-sn * a0[j] + cs * a1[j]) + nu2 * (-cs * a0[j] - sn * a1[j]);
             // rotation rows
             KP(NW, j) = cs * a0[j] + sn * a1[j];
@@ -677,21 +688,22 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
         for (int j = 0; j < 4; ++j) {
             const int a = OBCA_MAX_EDGES + j;
             KP(a, a) += dw + S.Einv[L.r_mu + k * 4 * L.nO + 4 * i + j];
-            Yv[a][3] = -S.bx[L.imu(k) + 4 * i + j];
-            Yv[a][0] = Ed * gd[a] * c0;
-            Yv[a][1] = Ed * gd[a] * c1;
-            Yv[a][2] = Ed * gd[a] * in.off * dth;
+            rl[a] = -S.bx[L.imu(k) + 4 * i + j];
+            Gm[a][0] = Ed * gd[a] * c0;
+            Gm[a][1] = Ed * gd[a] * c1;
+            Gm[a][2] = Ed * gd[a] * in.off * dth;
             KP(NW, a) = (j == 0) ? 1.0 : (j == 2) ? -1.0 : 0.0;
             KP(NW + 1, a) = (j == 1) ? 1.0 : (j == 3) ? -1.0 : 0.0;
         }
         KP(NW, NW) = 0.0; KP(NW + 1, NW) = 0.0; KP(NW + 1, NW + 1) = 0.0;
-        Yv[NW][0] = 0.0; Yv[NW][1] = 0.0; Yv[NW][2] = dth; Yv[NW][3] = -S.crot[2 * pr];
-        Yv[NW + 1][0] = 0.0; Yv[NW + 1][1] = 0.0; Yv[NW + 1][2] = -cs * c0 - sn * c1; Yv[NW + 1][3] = -S.crot[2 * pr + 1];
-        // LDL^T without pivoting (quasi-definite when the primal block is positive definite),
-        // forward substitution of the four right-hand sides fused into the elimination
+        Gm[NW][0] = 0.0; Gm[NW][1] = 0.0; Gm[NW][2] = dth; rl[NW] = -S.crot[2 * pr];
+        Gm[NW + 1][0] = 0.0; Gm[NW + 1][1] = 0.0; Gm[NW + 1][2] = -cs * c0 - sn * c1; rl[NW + 1] = -S.crot[2 * pr + 1];
+#pragma unroll
+        for (int a = 0; a < MW; ++a) { Yv[a][0] = hi ? Gm[a][2] : Gm[a][0]; Yv[a][1] = hi ? rl[a] : Gm[a][1]; }
+        // LDL^T without pivoting (quasi-definite when the primal block is positive definite), forward substitution
+        // fused.  Rectangular constant-trip loops with predicates: after full unrolling every index is a literal,
+        // so K and Yv live in registers (triangular bounds defeat the unroller and force them to scratch).
         double dinv[MW];
-        // rectangular constant-trip loops with predicates: after full unrolling every index is a literal,
-        // so K and Yv live in registers (triangular bounds defeat the unroller and force them to scratch)
 #pragma unroll
         for (int j = 0; j < MW; ++j) {
             const double d = KP(j, j);
@@ -710,27 +722,16 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
             for (int a = 0; a < MW; ++a) {
                 if (a > j) {
                     KP(a, j) *= dinv[j];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) Yv[a][c] -= KP(a, j) * Yv[j][c];
+                    Yv[a][0] -= KP(a, j) * Yv[j][0];
+                    Yv[a][1] -= KP(a, j) * Yv[j][1];
                 }
             }
         }
-        // Schur complement G' Kloc^-1 [G | rloc] = Z' D^-1 Z with Z = L^-1 [G | rloc]
-        double* So = S.Sloc + (size_t)pr * 12;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double v = 0.0;
-#pragma unroll
-                for (int e = 0; e < MW; ++e) v += Yv[e][a] * dinv[e] * Yv[e][c];
-                So[4 * a + c] = v;
-            }
 #pragma unroll
         for (int jj = 0; jj < MW; ++jj) {
             const int j = MW - 1 - jj;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 2; ++c) {
                 double v = Yv[j][c] * dinv[j];
 #pragma unroll
                 for (int a = 0; a < MW; ++a)
@@ -739,11 +740,18 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
             }
         }
 #undef KP
-        double* Yo = S.Y + (size_t)pr * (MW * 4);
+        // own two columns of Y = Kloc^-1 [G | rloc] and of the Schur complement G'Y
+        double* Yo = S.Y + (size_t)pr * (MW * 4) + (hi ? 2 : 0);
 #pragma unroll
-        for (int a = 0; a < MW; ++a)
+        for (int a = 0; a < MW; ++a) { Yo[4 * a] = Yv[a][0]; Yo[4 * a + 1] = Yv[a][1]; }
+        double* So = S.Sloc + (size_t)pr * 12 + (hi ? 2 : 0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) Yo[4 * a + c] = Yv[a][c];
+        for (int a = 0; a < 3; ++a) {
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < MW; ++e) { v0 += Gm[e][a] * Yv[e][0]; v1 += Gm[e][a] * Yv[e][1]; }
+            So[4 * a] = v0; So[4 * a + 1] = v1;
+        }
     }
     SYNC();
     // fold the Schur complements into the stage blocks
