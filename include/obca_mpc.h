@@ -76,7 +76,7 @@ enum {
     OBCA_E_INVAL = -22,                /* bad argument / shape beyond compiled limits             */
     OBCA_E_NOMEM = -12,
     OBCA_E_HIP = -5,                   /* a HIP runtime call failed                               */
-    OBCA_E_LDS = -28                   /* instance does not fit the 160 KiB LDS of one CU         */
+    OBCA_E_LDS = -28                   /* shape does not fit the LDS kernel (mode 1 only)         */
 };
 
 int obca_create(const obca_dims* dims, obca_handle** out);
@@ -104,11 +104,17 @@ int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
                      double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
                      double* info, void* hip_stream);
 
-/* Diagnostic: device buffer [max_batch,12] receiving per-phase shader-clock totals of each instance.
+/* Kernel selection: 0 = auto (default; also env OBCA_MODE): the wave-per-instance kernel whenever the shape fits one CU's
+ * LDS, else the lane-per-instance kernel; 1 = wave-per-instance (one wavefront per instance, working set in LDS);
+ * 2 = lane-per-instance (64 instances per wavefront, working set in an HBM workspace owned by the handle; any shape,
+ * e.g. N=20 with 5 obstacles).  Returns OBCA_E_LDS if mode 1 cannot hold the shape. */
+int obca_set_mode(obca_handle* h, int mode);
+
+/* Diagnostic: device buffer [max_batch,20] receiving per-phase shader-clock totals of each instance.
  * Only builds compiled with -DOBCA_PROFILE write to it; NULL (the default) disables it. */
 void obca_set_profile_buffer(obca_handle* h, double* prof);
 
-/* bytes of LDS one instance needs with these dims (<= 163840 or obca_create fails with OBCA_E_LDS) */
+/* bytes of LDS one instance needs in the wave-per-instance kernel (> 163840: only the lane kernel runs it) */
 int64_t obca_lds_bytes(const obca_dims* dims);
 
 const char* obca_strerror(int code);

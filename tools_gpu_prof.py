@@ -6,14 +6,14 @@ from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver impor
 B=int(sys.argv[1]) if len(sys.argv)>1 else 768
 b=sc.make_batch(B,5)
 s=BatchSolver(5,b['m'],B)
-prof=torch.zeros(B,12,dtype=torch.float64,device='cuda')
+prof=torch.zeros(B,20,dtype=torch.float64,device='cuda')
 s.lib.obca_set_profile_buffer(s._h, ctypes.c_void_p(prof.data_ptr()))
 for _ in range(2):
     out=s.solve(b['variant'],b['x0'],b['u0'],b['xref'],b['A'],b['b'],b['Ts'],b['term'],SolverParams())
 torch.cuda.synchronize()
 p=prof.cpu().numpy(); it=out.iters.cpu().numpy(); nf=out.info[:,3].cpu().numpy()
-names=['grad+err','mu','rowE+gatherB','asm_stages','local','riccati','rowsteps','linesearch','accept','reeval','-','loop']
-tot=p.sum(1)
+names=["grad+err","mu","rowE+gatherB","asm_stages","local","riccati","rowsteps","linesearch","accept","reeval","-","loop","r:FG+term","r:phaseA","r:phaseB","r:stage0","r:forward","r:recover","-","-"]
+tot=p[:,:12].sum(1)
 print('mean iters %.1f nfact %.1f total cycles/solve %.3e'%(it.mean(), nf.mean(), tot.mean()))
 for i,n in enumerate(names):
     print('%-14s %6.2f%%  cycles/iter %9.0f'%(n, 100*p[:,i].sum()/tot.sum(), p[:,i].sum()/it.sum()))

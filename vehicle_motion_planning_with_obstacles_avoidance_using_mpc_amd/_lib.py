@@ -33,7 +33,7 @@ class ObcaParams(ctypes.Structure):
 
 
 EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",
-           "obca_set_profile_buffer")
+           "obca_set_profile_buffer", "obca_set_mode")
 
 STATUS_OK, STATUS_ACCEPTABLE, STATUS_INFEASIBLE = 0, 1, 2
 STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NUMERIC, STATUS_BAD_BOUNDS = -1, -2, -3, -4
@@ -60,6 +60,8 @@ def load():
     lib.obca_solve_batch.restype = ctypes.c_int
     lib.obca_set_profile_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.obca_set_profile_buffer.restype = None
+    lib.obca_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.obca_set_mode.restype = ctypes.c_int
     lib.obca_lds_bytes.argtypes = [ctypes.POINTER(ObcaDims)]
     lib.obca_lds_bytes.restype = ctypes.c_int64
     lib.obca_strerror.argtypes = [ctypes.c_int]

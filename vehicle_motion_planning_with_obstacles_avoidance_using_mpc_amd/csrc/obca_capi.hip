@@ -5,10 +5,13 @@
 #include <new>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include "obca_device.h"
+#include "obca_lpi_core.h"
 
 extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A);
 extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A);
+extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm);
 
 struct obca_handle {
     obca_dims dims;
@@ -16,6 +19,12 @@ struct obca_handle {
     int32_t offm[OBCA_MAX_OBST + 1];
     int64_t lds_bytes;
     double* prof;
+    int mode;                 /* 0 auto, 1 wave-per-instance (LDS), 2 lane-per-instance (HBM workspace) */
+    bool wave_ok;             /* the LDS kernel can hold this shape */
+    double* ws;               /* lane kernel workspace, allocated on first use */
+    size_t ws_stride;
+    int* d_offm;
+    int64_t ws_doubles;
 };
 
 namespace {
@@ -77,9 +86,9 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
         h->offm[i + 1] = h->M;
     }
     h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
-    if (h->lds_bytes > 160 * 1024 || h->R_max > 384) { delete h; return OBCA_E_LDS; }   // rows live in registers: <= 6 per lane
+    h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
     if (hipSetDevice(d->device) != hipSuccess) { delete h; return OBCA_E_HIP; }
-    if (h->lds_bytes > 64 * 1024) {
+    if (h->wave_ok && h->lds_bytes > 64 * 1024) {
         const void* fn = h->R_max <= 256 ? reinterpret_cast<const void*>(obca_ipm_kernel_r4)
                                          : reinterpret_cast<const void*>(obca_ipm_kernel_r6);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
@@ -87,12 +96,29 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
             return OBCA_E_HIP;
         }
     }
+    h->mode = 0;
+    if (const char* e = getenv("OBCA_MODE")) h->mode = atoi(e);
+    h->ws = nullptr; h->d_offm = nullptr;
+    h->ws_stride = ((size_t)d->max_batch + 63) / 64 * 64;
+    h->ws_doubles = lpi::carve(d->N, d->n_obs, h->M, h->n_max, h->R_max).total;
     h->prof = nullptr;
     *out = h;
     return OBCA_OK;
 }
 
-extern "C" void obca_destroy(obca_handle* h) { delete h; }
+extern "C" void obca_destroy(obca_handle* h) {
+    if (!h) return;
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->d_offm) (void)hipFree(h->d_offm);
+    delete h;
+}
+
+extern "C" int obca_set_mode(obca_handle* h, int mode) {
+    if (!h || mode < 0 || mode > 2) return OBCA_E_INVAL;
+    if (mode == 1 && !h->wave_ok) return OBCA_E_LDS;
+    h->mode = mode;
+    return OBCA_OK;
+}
 
 extern "C" void obca_set_profile_buffer(obca_handle* h, double* prof) { if (h) h->prof = prof; }
 
@@ -138,10 +164,25 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     L.prm.opt.feas_tol = p->feas_tol > 0 ? p->feas_tol : 1e-6;
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
-    if (h->R_max <= 256)
-        hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
-    else
-        hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+    // wave kernel (working set in LDS) whenever the shape fits one CU; the lane kernel (working set in an HBM
+    // workspace, one instance per lane) takes the shapes beyond the LDS -- measured on MI355X it is latency bound
+    // (every access is an L2/HBM round trip at one wave per SIMD) and 4-10x slower where both run
+    bool lane = h->mode == 2 || !h->wave_ok;
+    if (h->mode == 1 && !h->wave_ok) return OBCA_E_LDS;
+    if (!lane) {
+        if (h->R_max <= 256)
+            hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+        else
+            hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+    } else {
+        if (!h->ws) {
+            if (hipMalloc(&h->ws, sizeof(double) * (size_t)h->ws_doubles * h->ws_stride) != hipSuccess) { h->ws = nullptr; return OBCA_E_NOMEM; }
+            if (hipMalloc(&h->d_offm, sizeof(int) * (OBCA_MAX_OBST + 1)) != hipSuccess) return OBCA_E_NOMEM;
+            if (hipMemcpy(h->d_offm, h->offm, sizeof(int) * (OBCA_MAX_OBST + 1), hipMemcpyHostToDevice) != hipSuccess) return OBCA_E_HIP;
+        }
+        hipLaunchKernelGGL(obca_lpi_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, L, h->ws,
+                           (unsigned long long)h->ws_stride, h->d_offm);
+    }
     if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
     return OBCA_OK;
 }

@@ -58,7 +58,7 @@ struct ObcaLaunch {
     double *xopt, *uopt, *ts_opt;
     int32_t *status, *iters;
     double* info;
-    double* prof;          /* [B,12] per-phase cycle counters, only written by -DOBCA_PROFILE builds */
+    double* prof;          /* [B,20] per-phase cycle counters, only written by -DOBCA_PROFILE builds */
     ObcaParamsDev prm;
 };
 

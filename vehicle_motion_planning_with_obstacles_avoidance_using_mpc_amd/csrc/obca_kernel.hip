@@ -21,11 +21,14 @@
 #define SYNC() __syncthreads()
 
 #ifdef OBCA_PROFILE
-#define PROF_DECL long long prof_t[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; long long prof_last = wall_clock64();
+#define PROF_DECL long long prof_last = wall_clock64();
 #define PROF(i) { const long long t_ = wall_clock64(); prof_t[i] += t_ - prof_last; prof_last = t_; }
+#define RPROF(i) { const long long t_ = wall_clock64(); prof_t[i] += t_ - rlast; rlast = t_; }
+__device__ long long* prof_dummy;
 #else
 #define PROF_DECL
 #define PROF(i)
+#define RPROF(i)
 #endif
 
 namespace {
@@ -853,7 +856,12 @@ __device__ __forceinline__ int soft_min_regs(const double* Pl, const double* ql,
 // stage matrix Mall = Lall + [F G]' P~ [F G]; (B) every lane inverts the 2x2 input block and produces one entry
 // of P_k / q_k / K.  Returns 1 on a wrong-sign pivot; on success dx (poses, inputs, T) and the multiplier steps
 // of the soft rows are written.
+#ifdef OBCA_PROFILE
+__device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, long long* prof_t) {
+    long long rlast = wall_clock64();
+#else
 __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
+#endif
 #ifdef NO_RICCATI
     return 0;
 #endif
@@ -892,6 +900,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         }
     }
     SYNC();
+    RPROF(12)
     for (int k = L.N - 1; k >= 0; --k) {
         // ---- phase A ----------------------------------------------------------------------------------
         double E[3], gh[3], X[36], qt[6], Mi[9];
@@ -925,6 +934,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
                 if (lane == c) S.Mik[9 * k + c] = Mi[c];
         }
         SYNC();
+        RPROF(13)
         // ---- phase B ----------------------------------------------------------------------------------
         const double m00 = S.Mall[8 * 6 + 6], m01 = 0.5 * (S.Mall[8 * 6 + 7] + S.Mall[8 * 7 + 6]), m11 = S.Mall[8 * 7 + 7];
         const double d1 = m11 - m01 * m01 / m00;
@@ -946,6 +956,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
             }
         }
         SYNC();
+        RPROF(14)
     }
     // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
     double E0[3], g0[3], X[36], qt[6], Mi0[9];
@@ -954,6 +965,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     bad |= soft_min_regs(S.Pk, S.qk, E0, X, qt, Mi0);
     if (L.free_T && !(X[35] > 0.0)) bad = 1;
     bad = wave_or(bad);
+    RPROF(15)
     if (bad) return 1;
     // ---- forward pass: every lane carries the (tiny) state redundantly, lane 0 stores
     double dT = 0.0;
@@ -1019,6 +1031,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         up[0] = u[0]; up[1] = u[1];
     }
     SYNC();
+    RPROF(16)
     // local recovery: [dw; dnu] = Y_r - Y_G dp_k
     for (int pr = lane; pr < L.npair; pr += 64) {
         const int k = pr / L.nO, i = pr - k * L.nO;
@@ -1033,6 +1046,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         }
     }
     SYNC();
+    RPROF(17)
     return 0;
 }
 
@@ -1214,6 +1228,10 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
     bool have_prev = false;
     double elastic_max = 0.0;
 
+#ifdef OBCA_PROFILE
+    long long prof_t[20];
+    for (int i = 0; i < 20; ++i) prof_t[i] = 0;
+#endif
     PROF_DECL
     if (bad_bounds) status = OBCA_STATUS_BAD_BOUNDS;
     else
@@ -1295,7 +1313,11 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
             PROF(3)
             int bad = local_blocks(L, S, in, delta_w, lane);
             PROF(4)
+#ifdef OBCA_PROFILE
+            if (!bad) bad = riccati(L, S, in, lane, prof_t);
+#else
             if (!bad) bad = riccati(L, S, in, lane);
+#endif
             PROF(5)
             ++nfact;
             if (!bad) break;
@@ -1479,7 +1501,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
         PROF(9)
     }
 #ifdef OBCA_PROFILE
-    if (A.prof && lane == 0) for (int i = 0; i < 12; ++i) A.prof[(size_t)inst * 12 + i] = (double)prof_t[i];
+    if (A.prof && lane == 0) for (int i = 0; i < 20; ++i) A.prof[(size_t)inst * 20 + i] = (double)prof_t[i];
 #endif
 
     if ((status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE) && elastic_max > O.feas_tol)

@@ -62,7 +62,7 @@ class BatchResult:
 class BatchSolver:
     """One handle = one problem shape (N, obstacle edge counts) on one GPU."""
 
-    def __init__(self, N, m, max_batch, device=None):
+    def __init__(self, N, m, max_batch, device=None, mode=None):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchSolver needs a ROCm GPU; there is no CPU fallback on the product path")
         self.lib = _lib.load()
@@ -81,6 +81,14 @@ class BatchSolver:
         _lib.check(self.lib.obca_create(ctypes.byref(d), ctypes.byref(h)))
         self._h = h
         self.lds_bytes = int(self.lib.obca_lds_bytes(ctypes.byref(d)))
+        if mode is not None:
+            self.set_mode(mode)
+
+    MODES = {"auto": 0, "wave": 1, "lane": 2}
+
+    def set_mode(self, mode):
+        """'auto' | 'wave' (one wavefront per instance, LDS) | 'lane' (64 instances per wavefront, HBM workspace)"""
+        _lib.check(self.lib.obca_set_mode(self._h, self.MODES.get(mode, mode)))
 
     def close(self):
         if getattr(self, "_h", None):
