@@ -166,3 +166,83 @@ def make_batch(B, N=5, seed0=SEED0, three_boxes=False, first=0):
         term=np.zeros((B, 3)),
     )
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Config C3: N = 20, walls + one static box + two moving 3x3 boxes crossing the corridor, lidar
+# gated -- gated instances are fixed-time solves (obca_mpc6, fallback obca_mpc8) with time-varying obstacle rows,
+# the others free-time solves (obca_mpc4) against the static obstacles only.
+def make_instance_c3(i, N=20, seed0=SEED0 + 10 ** 6, sense_dis=10.0):
+    rng = np.random.default_rng(seed0 + i)
+    om = obstacleModel()
+    for _ in range(400):
+        box = (rng.uniform(14, 28), rng.uniform(2.5, 7.5), rng.uniform(2, 4), rng.uniform(2, 4))
+        y0 = int(round(rng.uniform(3, 7)))
+        path = lattice_path(y0, box)
+        dyn = []
+        for _d in range(2):
+            up = rng.uniform() < 0.5
+            dyn.append(dict(cx=rng.uniform(10, 35), cy=rng.uniform(-6, -2) if up else rng.uniform(12, 16),
+                            th=math.pi / 2 if up else -math.pi / 2, v=rng.uniform(0.1, 0.5)))
+        noise = rng.uniform([-0.2, -0.2, -0.1], [0.2, 0.2, 0.1])
+        ts_fix = rng.uniform(1.8, 2.5)
+        if path is None or path.shape[1] < N + 3:
+            continue
+        i0 = int(rng.integers(0, path.shape[1] - N - 1))
+        x0 = path[:, i0] + noise
+        xref = window(path, x0, N)
+        if clearance(x0, box) < DMIN + 0.15 or clearance(xref[:, N], box) < DMIN + 0.15:
+            continue
+        dis = (xref[0, N] - x0[0]) + (xref[1, N] - x0[1])
+        seg = np.diff(xref[:2], axis=1)
+        length = float(np.sum(np.hypot(seg[0], seg[1])))
+        if dis / (N * V_MAX * TS) + 1.0 < 1.15 * length / (N * V_MAX * TS):
+            continue
+        rect = rectangle_vertices(box[0], box[1], 0.0, box[2], box[3])
+        static = [[[39, 9], [0, 9]], rect, [[0, 1], [39, 1]]]
+        front = (x0[0] + EGO[0] * math.cos(x0[2]), x0[1] + EGO[0] * math.sin(x0[2]))
+        gated = False
+        per_step = []
+        for k in range(N + 1):
+            polys = list(static)
+            for d in dyn:
+                cx = d["cx"] + ts_fix * d["v"] * math.cos(d["th"]) * k
+                cy = d["cy"] + ts_fix * d["v"] * math.sin(d["th"]) * k
+                verts = rectangle_vertices(cx, cy, d["th"], 3.0, 3.0)
+                polys.append(verts)
+                if k == 0 and any(math.hypot(front[0] - p[0], front[1] - p[1]) <= sense_dis for p in verts[:4]):
+                    gated = True
+            per_step.append(polys)
+        v_all = [len(p) for p in per_step[0]]
+        A = np.zeros((N + 1, sum(v_all) - len(v_all), 2))
+        b = np.zeros((N + 1, sum(v_all) - len(v_all)))
+        for k in range(N + 1):
+            Ak, bk = om.obstacle_H_Represent(len(per_step[k]), v_all, per_step[k])
+            A[k], b[k] = Ak, bk[:, 0]
+        return dict(x0=x0, u0=np.array([0.5, 0.0]), xref=xref, A=A, b=b, m=[n - 1 for n in v_all], gated=gated,
+                    Ts_fix=ts_fix, term=np.array([x0[0] + 5.0, 1.0, 9.0]), box=box, dyn=dyn)
+    raise RuntimeError("could not draw a C3 instance for seed %d" % (seed0 + i))
+
+
+def make_batch_c3(B, N=20, first=0, gated=True):
+    """gated=True: the fixed-time sub-batch (5 obstacles, variant 6); False: the free-time one (3 static, variant 4)."""
+    ins, i = [], first
+    while len(ins) < B:
+        q = make_instance_c3(i, N)
+        i += 1
+        if q["gated"] == gated:
+            ins.append(q)
+    if gated:
+        m = ins[0]["m"]
+        A = np.stack([q["A"] for q in ins])
+        b = np.stack([q["b"] for q in ins])
+        var, Ts = 6, np.array([q["Ts_fix"] for q in ins])
+    else:
+        m = ins[0]["m"][:3]
+        M = sum(m)
+        A = np.stack([q["A"][:, :M] for q in ins])
+        b = np.stack([q["b"][:, :M] for q in ins])
+        var, Ts = 4, np.full(B, TS)
+    return dict(m=m, variant=np.full(B, var, dtype=np.int32), x0=np.stack([q["x0"] for q in ins]),
+                u0=np.stack([q["u0"] for q in ins]), xref=np.stack([q["xref"] for q in ins]), A=A, b=b, Ts=Ts,
+                term=np.stack([q["term"] for q in ins]))
