@@ -513,86 +513,83 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
     const double h = T * in.Ts, ih2 = 1.0 / (h * h);
     double HTT = 0.0;
     for (int k = lane; k <= L.N; k += 64) {
-        double* H = S.Lall + 64 * k;
-        double* lv = S.lall + 8 * k;
-        for (int a = 0; a < 64; ++a) H[a] = 0.0;
+        // the stage block is accumulated in registers (read-modify-write through LDS serialised ~100 round trips)
+        double Hpp[3][3], Huu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, Cpu[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        double hpu = 0.0, hpT = 0.0, huT[2] = {0.0, 0.0};
         const double cs = S.ct[k], sn = S.st[k];
         const double* W = (k < L.N) ? in.Q : in.P;
+#pragma unroll
         for (int a = 0; a < 3; ++a) {
-            for (int b = 0; b < 3; ++b) H[8 * a + b] = sf * 2.0 * W[3 * a + b];
-            H[8 * a + a] += dw;
-            lv[a] = S.bx[L.ip(k) + a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Hpp[a][b] = sf * 2.0 * W[3 * a + b];
+            Hpp[a][a] += dw;
         }
-        lv[3] = lv[4] = lv[5] = 0.0;
-        for (int j = 0; j < 2; ++j) {                               // position box rows
-            H[8 * j + j] += S.Einv[L.r_xb + 2 * k + j];
-        }
-        if (k == L.N && L.variant == 4) for (int j = 0; j < 3; ++j) H[8 * j + j] += S.Einv[L.r_term + j];
-        if (k == L.N && L.variant == 6) for (int j = 0; j < 2; ++j) H[8 * j + j] += S.Einv[L.r_tx + j];
+        Hpp[0][0] += S.Einv[L.r_xb + 2 * k];
+        Hpp[1][1] += S.Einv[L.r_xb + 2 * k + 1];
+        if (k == L.N && L.variant == 4) { Hpp[0][0] += S.Einv[L.r_term]; Hpp[1][1] += S.Einv[L.r_term + 1]; Hpp[2][2] += S.Einv[L.r_term + 2]; }
+        if (k == L.N && L.variant == 6) { Hpp[0][0] += S.Einv[L.r_tx]; Hpp[1][1] += S.Einv[L.r_tx + 1]; }
         double hth = 0.0;                                           // theta-theta Lagrangian curvature
         for (int i = 0; i < L.nO; ++i) {
             const int pr = k * L.nO + i;
             const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
             const double yd = S.y[L.r_dist + pr], Ei = S.Einv[L.r_dist + pr];
             const double gp[3] = {c0, c1, in.off * (-sn * c0 + cs * c1)};
+#pragma unroll
             for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b) H[8 * a + b] += Ei * gp[a] * gp[b];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) Hpp[a][b] += Ei * gp[a] * gp[b];
             hth += yd * in.off * (-cs * c0 - sn * c1);
             hth += S.nu[2 * pr] * (-cs * c0 - sn * c1) + S.nu[2 * pr + 1] * (sn * c0 - cs * c1);
         }
+        double lu0 = 0.0, lu1 = 0.0;
         if (k < L.N) {
             const double* u = xv + L.iu(k);
             const double* yd = S.y + L.r_dyn + 3 * k;
-            hth += h * u[0] * (yd[0] * cs + yd[1] * sn);
-            const double hpu = h * (yd[0] * sn - yd[1] * cs);       // theta - v
-            H[8 * 2 + 6] += hpu;
-            H[8 * 6 + 2] += hpu;
+            const double u0 = u[0], u1 = u[1], y0 = yd[0], y1 = yd[1], y2 = yd[2];
+            hth += h * u0 * (y0 * cs + y1 * sn);
+            hpu = h * (y0 * sn - y1 * cs);                            // theta - v
+            const int ncost = (k + 1 < L.N ? 1 : 0) + (k >= 1 ? 1 : 0);  // acceleration cost pairs touching u_k
+#pragma unroll
             for (int a = 0; a < 2; ++a) {
-                for (int b = 0; b < 2; ++b) H[8 * (6 + a) + 6 + b] = sf * 2.0 * in.R1[2 * a + b];
-                H[8 * (6 + a) + 6 + a] += dw + S.Einv[L.r_ub + 2 * k + a];
-                lv[6 + a] = S.bx[L.iu(k) + a];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    Huu[a][b] = sf * 2.0 * in.R1[2 * a + b] + sf * 2.0 * in.R2[2 * a + b] * ih2 * ncost;
+                    if (k >= 1) Cpu[a][b] = -sf * 2.0 * in.R2[2 * a + b] * ih2;
+                }
+                Huu[a][a] += dw + S.Einv[L.r_ub + 2 * k + a];
             }
-            // acceleration cost couples u_k with u_{k-1} (stage k) and u_{k+1} (stage k+1)
-            const int ncost = (k + 1 < L.N ? 1 : 0) + (k >= 1 ? 1 : 0);
-            for (int a = 0; a < 2; ++a)
-                for (int b = 0; b < 2; ++b) H[8 * (6 + a) + 6 + b] += sf * 2.0 * in.R2[2 * a + b] * ih2 * ncost;
-            if (k >= 1)
-                for (int a = 0; a < 2; ++a)
-                    for (int b = 0; b < 2; ++b) {
-                        const double v = -sf * 2.0 * in.R2[2 * a + b] * ih2;
-                        H[8 * (3 + a) + 6 + b] += v;
-                        H[8 * (6 + b) + 3 + a] += v;
-                    }
+            lu0 = S.bx[L.iu(k)]; lu1 = S.bx[L.iu(k) + 1];
             // acceleration rows k (u_{k-1}, u_k) and k+1 (u_k, u_{k+1})
+#pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const double Ek = S.Einv[L.r_acc + 2 * k + c];
-                H[8 * (6 + c) + 6 + c] += Ek * ih2;
-                if (k >= 1) {
-                    H[8 * (3 + c) + 6 + c] -= Ek * ih2;
-                    H[8 * (6 + c) + 3 + c] -= Ek * ih2;
-                }
-                if (k + 1 < L.N) H[8 * (6 + c) + 6 + c] += S.Einv[L.r_acc + 2 * (k + 1) + c] * ih2;
+                Huu[c][c] += Ek * ih2;
+                if (k >= 1) Cpu[c][c] -= Ek * ih2;
+                if (k + 1 < L.N) Huu[c][c] += S.Einv[L.r_acc + 2 * (k + 1) + c] * ih2;
             }
             if (L.free_T) {
                 // (theta,T), (u,T) and (T,T) entries
-                double hpT = -in.Ts * u[0] * (-yd[0] * sn + yd[1] * cs);
-                double huT[2] = {-in.Ts * (yd[0] * cs + yd[1] * sn), -in.Ts * yd[2]};
+                hpT = -in.Ts * u0 * (-y0 * sn + y1 * cs);
+                huT[0] = -in.Ts * (y0 * cs + y1 * sn);
+                huT[1] = -in.Ts * y2;
+                const double uc[2] = {u0, u1};
+                double qa[2] = {0, 0}, qb[2] = {0, 0};
+                if (k + 1 < L.N) { qa[0] = xv[L.iu(k + 1)] - u0; qa[1] = xv[L.iu(k + 1) + 1] - u1; }
+                if (k >= 1) { qb[0] = u0 - xv[L.iu(k - 1)]; qb[1] = u1 - xv[L.iu(k - 1) + 1]; }
+#pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
-                    const double q = prev - u[c];
+                    const double q = (k == 0) ? in.u0[c] - uc[c] : -qb[c];     // u_{k-1} - u_k
                     const double ya = S.y[L.r_acc + 2 * k + c], Ek = S.Einv[L.r_acc + 2 * k + c];
                     huT[c] += ya / (T * h) + Ek * q / (T * h * h);
                     HTT += ya * 2.0 * q / (T * T * h) + Ek * q * q / (T * T * h * h);
                     if (k + 1 < L.N) {
-                        const double qn = u[c] - xv[L.iu(k + 1) + c];
+                        const double qn = -qa[c];                              // u_k - u_{k+1}
                         const double yn = S.y[L.r_acc + 2 * (k + 1) + c], En = S.Einv[L.r_acc + 2 * (k + 1) + c];
                         huT[c] += -yn / (T * h) - En * qn / (T * h * h);
                     }
                 }
                 // acceleration cost cross terms
-                double qa[2] = {0, 0}, qb[2] = {0, 0};
-                if (k + 1 < L.N) { qa[0] = xv[L.iu(k + 1)] - u[0]; qa[1] = xv[L.iu(k + 1) + 1] - u[1]; }
-                if (k >= 1) { qb[0] = u[0] - xv[L.iu(k - 1)]; qb[1] = u[1] - xv[L.iu(k - 1) + 1]; }
+#pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const double Ra = in.R2[2 * a] * qa[0] + in.R2[2 * a + 1] * qa[1];
                     const double Rb = in.R2[2 * a] * qb[0] + in.R2[2 * a + 1] * qb[1];
@@ -602,14 +599,31 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
                     const double qq = qa[0] * (in.R2[0] * qa[0] + in.R2[1] * qa[1]) + qa[1] * (in.R2[2] * qa[0] + in.R2[3] * qa[1]);
                     HTT += sf * 6.0 * qq * ih2 / (T * T);
                 }
-                H[8 * 2 + 5] += hpT; H[8 * 5 + 2] += hpT;
-                for (int c = 0; c < 2; ++c) { H[8 * (6 + c) + 5] += huT[c]; H[8 * 5 + 6 + c] += huT[c]; }
             }
         } else {
-            lv[6] = lv[7] = 0.0;
-            H[8 * 6 + 6] = 1.0; H[8 * 7 + 7] = 1.0;     // no input at the last stage
+            Huu[0][0] = 1.0; Huu[1][1] = 1.0;             // no input at the last stage
         }
-        H[8 * 2 + 2] += hth;
+        Hpp[2][2] += hth;
+        // write the 8x8 block over (dp(0:3), du_prev(3:5), dT(5), du(6:8)) and its gradient
+        double* H = S.Lall + 64 * k;
+        double* lv = S.lall + 8 * k;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                double v = 0.0;
+                if (a < 3 && b < 3) v = Hpp[a][b];
+                else if (a >= 6 && b >= 6) v = Huu[a - 6][b - 6];
+                else if (a >= 3 && a < 5 && b >= 6) v = Cpu[a - 3][b - 6];
+                else if (b >= 3 && b < 5 && a >= 6) v = Cpu[b - 3][a - 6];
+                else if ((a == 2 && b == 6) || (a == 6 && b == 2)) v = hpu;
+                else if ((a == 2 && b == 5) || (a == 5 && b == 2)) v = hpT;
+                else if (a == 5 && b >= 6) v = huT[b - 6];
+                else if (b == 5 && a >= 6) v = huT[a - 6];
+                H[8 * a + b] = v;
+            }
+        lv[0] = S.bx[L.ip(k)]; lv[1] = S.bx[L.ip(k) + 1]; lv[2] = S.bx[L.ip(k) + 2];
+        lv[3] = 0.0; lv[4] = 0.0; lv[5] = 0.0; lv[6] = lu0; lv[7] = lu1;
     }
     if (L.free_T) {
         HTT = wave_sum(HTT);
@@ -957,6 +971,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         }
         SYNC();
         RPROF(14)
+        if (wave_or(bad)) return 1;         // wrong-sign pivot: the attempt is over, no need to finish the sweep
     }
     // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
     double E0[3], g0[3], X[36], qt[6], Mi0[9];
@@ -989,41 +1004,45 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         if (L.free_T) S.dx[L.iT()] = dT;
     }
     for (int k = 0; k < L.N; ++k) {
-        const double* Kg = S.Kk + 12 * k;
-        const double xi[6] = {dp[0], dp[1], dp[2], up[0], up[1], dT};
-        double u[2];
+        // all operands of the stage first (independent LDS reads, one wait), then the arithmetic
+        double Kg[12], P1[18], Mi[9], q1[3], E[3], gh[3];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            double v = S.kapk[2 * k + c];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) v += Kg[6 * c + a] * xi[a];
-            u[c] = v;
-        }
-        const double cs = S.ct[k], sn = S.st[k];
-        const double* uk = xv + L.iu(k);
-        double ph[3];
-        ph[0] = dp[0] - h * uk[0] * sn * dp[2] + h * cs * u[0] - S.gh[L.r_dyn + 3 * k];
-        ph[1] = dp[1] + h * uk[0] * cs * dp[2] + h * sn * u[0] - S.gh[L.r_dyn + 3 * k + 1];
-        ph[2] = dp[2] + h * u[1] - S.gh[L.r_dyn + 3 * k + 2];
-        if (L.free_T) { ph[0] += in.Ts * uk[0] * cs * dT; ph[1] += in.Ts * uk[0] * sn * dT; ph[2] += in.Ts * uk[1] * dT; }
-        const double* P1 = S.Pk + 36 * (k + 1);
-        const double* q1 = S.qk + 6 * (k + 1);
-        const double* Mi = S.Mik + 9 * k;
-        double t[3], dn[3];
+        for (int a = 0; a < 12; ++a) Kg[a] = S.Kk[12 * k + a];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double E = 1.0 / S.Einv[L.r_dyn + 3 * k + a];
-            t[a] = ph[a] - E * (P1[6 * a + 3] * u[0] + P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) P1[6 * a + c] = S.Pk[36 * (k + 1) + 6 * a + c];
+            q1[a] = S.qk[6 * (k + 1) + a];
+            E[a] = S.Einv[L.r_dyn + 3 * k + a];
+            gh[a] = S.gh[L.r_dyn + 3 * k + a];
         }
 #pragma unroll
+        for (int a = 0; a < 9; ++a) Mi[a] = S.Mik[9 * k + a];
+        const double kap0 = S.kapk[2 * k], kap1 = S.kapk[2 * k + 1];
+        const double cs = S.ct[k], sn = S.st[k];
+        const double uk0 = xv[L.iu(k)], uk1 = xv[L.iu(k) + 1];
+        const double xi[6] = {dp[0], dp[1], dp[2], up[0], up[1], dT};
+        double u[2] = {kap0, kap1};
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { u[0] += Kg[a] * xi[a]; u[1] += Kg[6 + a] * xi[a]; }
+        double ph[3];
+        ph[0] = dp[0] - h * uk0 * sn * dp[2] + h * cs * u[0] - gh[0];
+        ph[1] = dp[1] + h * uk0 * cs * dp[2] + h * sn * u[0] - gh[1];
+        ph[2] = dp[2] + h * u[1] - gh[2];
+        if (L.free_T) { ph[0] += in.Ts * uk0 * cs * dT; ph[1] += in.Ts * uk0 * sn * dT; ph[2] += in.Ts * uk1 * dT; }
+        double t[3], dn[3], dyv[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            t[a] = ph[a] - (P1[6 * a + 3] * u[0] + P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]) / E[a];
+#pragma unroll
         for (int a = 0; a < 3; ++a) dn[a] = Mi[a] * t[0] + Mi[3 + a] * t[1] + Mi[6 + a] * t[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            dyv[a] = -(P1[6 * a] * dn[0] + P1[6 * a + 1] * dn[1] + P1[6 * a + 2] * dn[2] + P1[6 * a + 3] * u[0] +
+                       P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]);
         if (lane == 0) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                S.dy[L.r_dyn + 3 * k + a] = -(P1[6 * a] * dn[0] + P1[6 * a + 1] * dn[1] + P1[6 * a + 2] * dn[2] +
-                                              P1[6 * a + 3] * u[0] + P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]);
-                S.dx[L.ip(k + 1) + a] = dn[a];
-            }
+            for (int a = 0; a < 3; ++a) { S.dy[L.r_dyn + 3 * k + a] = dyv[a]; S.dx[L.ip(k + 1) + a] = dn[a]; }
             S.dx[L.iu(k)] = u[0];
             S.dx[L.iu(k) + 1] = u[1];
         }
