@@ -165,7 +165,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "obca_ipm_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_instance": ab,
-                         "note": "latency/fp64-VALU bound by design (SURVEY 8d): ~1.3 KB of HBM traffic per solve"},
+                         "fp64_model_frac": value / world * (nf_sum / total) * (N + 1) * (32 ** 3 / 3 + 2 * 32 ** 2) / 78.6e12
+                         if M == 6 else None,
+                         "note": "latency/fp64-VALU bound by design (SURVEY 8d): ~1.3 KB of HBM traffic per solve; "
+                                 "fp64_model_frac = steps/s x KKT factorisations x (N+1)(s^3/3+2s^2), s=32, over 78.6 TF"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)

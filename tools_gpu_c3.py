@@ -1,0 +1,20 @@
+import sys, time, numpy as np, torch
+sys.path.insert(0,'.')
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+B=int(sys.argv[1]) if len(sys.argv)>1 else 1024
+N=int(sys.argv[2]) if len(sys.argv)>2 else 20
+for gated in (False, True):
+    base=sc.make_batch_c3(64,N,gated=gated)
+    rep=(B+63)//64
+    b={k:(np.concatenate([v]*rep)[:B] if isinstance(v,np.ndarray) else v) for k,v in base.items()}
+    s=BatchSolver(N,b['m'],B)
+    dv={k:torch.as_tensor(b[k],device='cuda') for k in ('variant','x0','u0','xref','A','b','Ts','term')}
+    out=None
+    for i in range(2):
+        torch.cuda.synchronize(); t=time.time()
+        out=s.solve(dv['variant'],dv['x0'],dv['u0'],dv['xref'],dv['A'],dv['b'],dv['Ts'],dv['term'],SolverParams(),out=out)
+        torch.cuda.synchronize(); dt=time.time()-t
+    st=out.status.cpu().numpy()
+    print('C3 N=%d gated=%s B=%d: %.1f ms -> %.0f solves/s, ok %.3f, mean iters %.1f nfact %.1f'%(N,gated,B,dt*1e3,B/dt,np.mean((st==0)|(st==1)),out.iters.float().mean().item(),out.info[:,3].mean().item()), flush=True)
+    s.close()

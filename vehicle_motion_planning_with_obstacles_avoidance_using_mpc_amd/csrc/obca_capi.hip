@@ -11,7 +11,7 @@
 
 extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A);
 extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A);
-extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm);
+extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
 struct obca_handle {
     obca_dims dims;
@@ -180,8 +180,10 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
             if (hipMalloc(&h->d_offm, sizeof(int) * (OBCA_MAX_OBST + 1)) != hipSuccess) return OBCA_E_NOMEM;
             if (hipMemcpy(h->d_offm, h->offm, sizeof(int) * (OBCA_MAX_OBST + 1), hipMemcpyHostToDevice) != hipSuccess) return OBCA_E_HIP;
         }
-        hipLaunchKernelGGL(obca_lpi_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, L, h->ws,
-                           (unsigned long long)h->ws_stride, h->d_offm);
+        int ipw = 64;                               // one wave per SIMD (256 CUs x 4) before the waves get fatter
+        while (ipw > 1 && (B + ipw - 1) / ipw < 1024) ipw >>= 1;
+        hipLaunchKernelGGL(obca_lpi_kernel, dim3((B + ipw - 1) / ipw), dim3(64), 0, (hipStream_t)hip_stream, L, h->ws,
+                           (unsigned long long)h->ws_stride, h->d_offm, ipw);
     }
     if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
     return OBCA_OK;

@@ -5,8 +5,11 @@
 #include "obca_lpi_core.h"
 
 extern "C" __global__ void __launch_bounds__(64)
-obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm) {
-    const size_t inst = (size_t)blockIdx.x * 64 + threadIdx.x;
+obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw) {
+    // ipw instances per wavefront (<= 64): the kernel is bound by memory latency, so small batches are spread over
+    // more, thinner waves to put one on every SIMD of the chip
+    if ((int)threadIdx.x >= ipw) return;
+    const size_t inst = (size_t)blockIdx.x * ipw + threadIdx.x;
     if (inst >= (size_t)A.B) return;
     lpi::run_instance(A, ws, (size_t)stride, inst, offm);
 }

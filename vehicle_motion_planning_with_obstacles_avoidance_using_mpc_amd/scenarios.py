@@ -228,7 +228,11 @@ def make_batch_c3(B, N=20, first=0, gated=True):
     """gated=True: the fixed-time sub-batch (5 obstacles, variant 6); False: the free-time one (3 static, variant 4)."""
     ins, i = [], first
     while len(ins) < B:
-        q = make_instance_c3(i, N)
+        try:
+            q = make_instance_c3(i, N)
+        except RuntimeError:                 # no admissible window for this seed: the seed is skipped
+            i += 1
+            continue
         i += 1
         if q["gated"] == gated:
             ins.append(q)
