@@ -48,7 +48,7 @@ int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off)
     int64_t t = 0;
     auto take = [&](int64_t c) { t += (c + 1) & ~int64_t(1); };
     for (int i = 0; i < 5; ++i) take(n_max);                    // x, xt, dx, gf, bx
-    for (int i = 0; i < 5; ++i) take(R_max);                    // y, Einv, yhat, gh, tmp
+    for (int i = 0; i < 7; ++i) take(R_max);                    // y, Einv, yhat, gh, tmp, Lb, Ub
     take(3 * N1 + 3);                                           // dy of the soft rows
     take(N1); take(N1); take(2 * np); take(N1); take(N1); take(2 * np);
     take(2 * np); take(2 * np); take(2 * np);

@@ -41,7 +41,8 @@ constexpr int NW = OBCA_MAX_EDGES + 4;      // primal part of the local block
 // past the 64 KiB instruction cache.  One shared copy each.
 __device__ __noinline__ double dlog(double x) { return log(x); }
 __device__ __noinline__ double dpow(double x, double y) { return exp(y * log(x)); }
-__device__ __noinline__ void dsincos(double x, double* s, double* c) { sincos(x, s, c); }
+struct SinCos { double s, c; };
+__device__ __noinline__ SinCos dsincos(double x) { SinCos r; r.s = sin(x); r.c = cos(x); return r; }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 // DPP within each row of 16 lanes (no LDS crossbar: __shfl_xor lowers to ds_bpermute, ~12 dependent LDS
@@ -96,6 +97,7 @@ static_assert(sizeof(Inst) <= OBCA_INST_DOUBLES * sizeof(double), "Inst does not
 struct Sh {
     double *x, *xt, *dx, *gf, *bx;
     double *y, *Einv, *yhat, *gh, *dy, *tmp; // row data other lanes read (dy: soft rows only); tmp: staging
+    double *Lb, *Ub;                         // row bounds (read-only after initialisation)
     double *ct, *st, *cc, *ctt, *stt, *cct;
     double *nu, *dnu, *crot;
     double *Aobs, *bobs, *xref;
@@ -120,10 +122,9 @@ __device__ __forceinline__ bool row_soft(const Lay& L, int r) { return r < L.r_t
 __device__ void eval_geom(const Lay& L, const Sh& S, const double* xv, double* ct, double* st, double* cc,
                           int lane) {
     for (int k = lane; k <= L.N; k += 64) {
-        double sn, cs;
-        dsincos(xv[L.ip(k) + 2], &sn, &cs);
-        ct[k] = cs;
-        st[k] = sn;
+        const SinCos sc = dsincos(xv[L.ip(k) + 2]);
+        ct[k] = sc.c;
+        st[k] = sc.s;
     }
     for (int pr = lane; pr < L.npair; pr += 64) {
         const int k = pr / L.nO, i = pr - k * L.nO;
@@ -426,15 +427,15 @@ __device__ double row_jdx(const Lay& L, const Sh& S, const Inst& in, int r) {
 // need goes to LDS: y (gather / curvature), yhat, Einv, ghat (assembly, Riccati).
 template <int RPL>
 struct Rows {
-    double lo[RPL], up[RPL], s[RPL], p[RPL], n[RPL], y[RPL], zL[RPL], zU[RPL], zp[RPL], zn[RPL], g[RPL], dy[RPL];
+    double s[RPL], p[RPL], n[RPL], y[RPL], zL[RPL], zU[RPL], zp[RPL], zn[RPL], g[RPL], dy[RPL];
     double iDs[RPL], iDp[RPL], iDn[RPL], rs[RPL], rp[RPL], rn[RPL];
 };
 
 struct Err { double E, dual, prim, comp; };
 
 template <int RPL>
-__device__ Err ipm_errors(const Lay& L, const Rows<RPL>& W, double mu, double rho, double rxmax, double crotmax,
-                          double nusum, int lane) {
+__device__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double mu, double rho, double rxmax,
+                          double crotmax, double nusum, int lane) {
     double dual = 0.0, prim = 0.0, comp = 0.0, ysum = 0.0, zsum = 0.0, nz = 0.0, nrow = 0.0;
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
@@ -442,7 +443,8 @@ __device__ Err ipm_errors(const Lay& L, const Rows<RPL>& W, double mu, double rh
         if (r < L.R) {
             const double w = row_w(L, r);
             const bool eq = row_iseq(L, r);
-            const bool hasL = !eq && W.lo[j] > -INFINITY, hasU = !eq && W.up[j] < INFINITY;
+            const double lo_ = S.Lb[r], up_ = S.Ub[r];
+            const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
             const double s = W.s[j], y = W.y[j], p = W.p[j], n = W.n[j];
             const double zL = hasL ? W.zL[j] : 0.0, zU = hasU ? W.zU[j] : 0.0, zp = W.zp[j], zn = W.zn[j];
             if (!eq) dual = dmaxabs(dual, -y - zL + zU);
@@ -451,8 +453,8 @@ __device__ Err ipm_errors(const Lay& L, const Rows<RPL>& W, double mu, double rh
             prim = dmaxabs(prim, W.g[j] - (eq ? 0.0 : s) - p + n);
             comp = dmaxabs(comp, p * zp - mu);
             comp = dmaxabs(comp, n * zn - mu);
-            if (hasL) comp = dmaxabs(comp, (s - W.lo[j]) * zL - mu);
-            if (hasU) comp = dmaxabs(comp, (W.up[j] - s) * zU - mu);
+            if (hasL) comp = dmaxabs(comp, (s - lo_) * zL - mu);
+            if (hasU) comp = dmaxabs(comp, (up_ - s) * zU - mu);
             ysum += w * fabs(y);
             zsum += w * (zL + zU + zp + zn);
             nz += w * ((hasL ? 1.0 : 0.0) + (hasU ? 1.0 : 0.0) + 2.0);
@@ -662,7 +664,7 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
         const double yd = S.y[L.r_dist + pr], Ed = S.Einv[L.r_dist + pr];
         const double nu1 = S.nu[2 * pr], nu2 = S.nu[2 * pr + 1];
         double a0[OBCA_MAX_EDGES], a1[OBCA_MAX_EDGES], gn[OBCA_MAX_EDGES], gd[NW];
-        double K[MW * (MW + 1) / 2], Yv[MW][2], Gm[MW][3];
+        double K[MW * (MW + 1) / 2], Yv[MW][2], G0[MW], G1[MW], G2[MW];
 #define KP(a, b) K[((a) * ((a) + 1)) / 2 + (b)]
         const double dth = -sn * c0 + cs * c1;          // d(dist)/d(theta) / off  and  d(e1)/d(theta)
 #pragma unroll
@@ -693,9 +695,9 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
             KP(j, j) += on ? (dw + S.Einv[L.r_lam + k * L.M + o0 + j]) : 1.0;   // padded slots: identity
             rl[j] = on ? -S.bx[L.il(k) + o0 + j] : 0.0;
             // coupling to the pose: columns (x, y, theta)
-            Gm[j][0] = Ed * gd[j] * c0 + yd * a0[j];
-            Gm[j][1] = Ed * gd[j] * c1 + yd * a1[j];
-            Gm[j][2] = Ed * gd[j] * in.off * dth + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
+            G0[j] = Ed * gd[j] * c0 + yd * a0[j];
+            G1[j] = Ed * gd[j] * c1 + yd * a1[j];
+            G2[j] = Ed * gd[j] * in.off * dth + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
                        nu1 * (-sn * a0[j] + cs * a1[j]) + nu2 * (-cs * a0[j] - sn * a1[j]);
             // rotation rows
             KP(NW, j) = cs * a0[j] + sn * a1[j];
@@ -706,17 +708,17 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
             const int a = OBCA_MAX_EDGES + j;
             KP(a, a) += dw + S.Einv[L.r_mu + k * 4 * L.nO + 4 * i + j];
             rl[a] = -S.bx[L.imu(k) + 4 * i + j];
-            Gm[a][0] = Ed * gd[a] * c0;
-            Gm[a][1] = Ed * gd[a] * c1;
-            Gm[a][2] = Ed * gd[a] * in.off * dth;
+            G0[a] = Ed * gd[a] * c0;
+            G1[a] = Ed * gd[a] * c1;
+            G2[a] = Ed * gd[a] * in.off * dth;
             KP(NW, a) = (j == 0) ? 1.0 : (j == 2) ? -1.0 : 0.0;
             KP(NW + 1, a) = (j == 1) ? 1.0 : (j == 3) ? -1.0 : 0.0;
         }
         KP(NW, NW) = 0.0; KP(NW + 1, NW) = 0.0; KP(NW + 1, NW + 1) = 0.0;
-        Gm[NW][0] = 0.0; Gm[NW][1] = 0.0; Gm[NW][2] = dth; rl[NW] = -S.crot[2 * pr];
-        Gm[NW + 1][0] = 0.0; Gm[NW + 1][1] = 0.0; Gm[NW + 1][2] = -cs * c0 - sn * c1; rl[NW + 1] = -S.crot[2 * pr + 1];
+        G0[NW] = 0.0; G1[NW] = 0.0; G2[NW] = dth; rl[NW] = -S.crot[2 * pr];
+        G0[NW + 1] = 0.0; G1[NW + 1] = 0.0; G2[NW + 1] = -cs * c0 - sn * c1; rl[NW + 1] = -S.crot[2 * pr + 1];
 #pragma unroll
-        for (int a = 0; a < MW; ++a) { Yv[a][0] = hi ? Gm[a][2] : Gm[a][0]; Yv[a][1] = hi ? rl[a] : Gm[a][1]; }
+        for (int a = 0; a < MW; ++a) { Yv[a][0] = hi ? G2[a] : G0[a]; Yv[a][1] = hi ? rl[a] : G1[a]; }
         // LDL^T without pivoting (quasi-definite when the primal block is positive definite), forward substitution
         // fused.  Rectangular constant-trip loops with predicates: after full unrolling every index is a literal,
         // so K and Yv live in registers (triangular bounds defeat the unroller and force them to scratch).
@@ -762,12 +764,15 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
 #pragma unroll
         for (int a = 0; a < MW; ++a) { Yo[4 * a] = Yv[a][0]; Yo[4 * a + 1] = Yv[a][1]; }
         double* So = S.Sloc + (size_t)pr * 12 + (hi ? 2 : 0);
+        {
+            double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0, s20 = 0.0, s21 = 0.0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-            for (int e = 0; e < MW; ++e) { v0 += Gm[e][a] * Yv[e][0]; v1 += Gm[e][a] * Yv[e][1]; }
-            So[4 * a] = v0; So[4 * a + 1] = v1;
+            for (int e = 0; e < MW; ++e) {
+                s00 += G0[e] * Yv[e][0]; s01 += G0[e] * Yv[e][1];
+                s10 += G1[e] * Yv[e][0]; s11 += G1[e] * Yv[e][1];
+                s20 += G2[e] * Yv[e][0]; s21 += G2[e] * Yv[e][1];
+            }
+            So[0] = s00; So[1] = s01; So[4] = s10; So[5] = s11; So[8] = s20; So[9] = s21;
         }
     }
     SYNC();
@@ -1106,7 +1111,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
         auto take = [&](int cnt) { double* q = p; p += (cnt + 1) & ~1; return q; };
         const int nmax = A.n_max, Rmax = A.R_max, np = L.npair, N1 = L.N + 1;
         S.x = take(nmax); S.xt = take(nmax); S.dx = take(nmax); S.gf = take(nmax); S.bx = take(nmax);
-        S.y = take(Rmax); S.Einv = take(Rmax); S.yhat = take(Rmax); S.gh = take(Rmax); S.tmp = take(Rmax); S.dy = take(3 * N1 + 3);
+        S.y = take(Rmax); S.Einv = take(Rmax); S.yhat = take(Rmax); S.gh = take(Rmax); S.tmp = take(Rmax); S.Lb = take(Rmax); S.Ub = take(Rmax); S.dy = take(3 * N1 + 3);
         S.ct = take(N1); S.st = take(N1); S.cc = take(2 * np); S.ctt = take(N1); S.stt = take(N1); S.cct = take(2 * np);
         S.nu = take(2 * np); S.dnu = take(2 * np); S.crot = take(2 * np);
         S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
@@ -1194,17 +1199,17 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
         for (int r = lane; r < L.R; r += 64) {
             double lo, up;
             row_bounds(L, in, r, lo, up);
-            S.Einv[r] = lo; S.gh[r] = up;
+            S.Lb[r] = lo; S.Ub[r] = up;
             S.tmp[r] = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
         }
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
             const int r = lane + 64 * j;
-            W.lo[j] = 0.0; W.up[j] = 0.0; W.s[j] = 0.0; W.p[j] = 1.0; W.n[j] = 1.0; W.y[j] = 0.0;
+            W.s[j] = 0.0; W.p[j] = 1.0; W.n[j] = 1.0; W.y[j] = 0.0;
             W.zL[j] = 0.0; W.zU[j] = 0.0; W.zp[j] = 1.0; W.zn[j] = 1.0; W.g[j] = 0.0; W.dy[j] = 0.0;
             W.iDs[j] = 0.0; W.iDp[j] = 1.0; W.iDn[j] = 1.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
             if (r < L.R) {
-                const double lo = S.Einv[r], up = S.gh[r];
+                const double lo = S.Lb[r], up = S.Ub[r];
                 const bool eq = row_iseq(L, r);
                 const double g = S.tmp[r];
                 double s = g;
@@ -1221,7 +1226,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
                 const double a = (mu - rho * rr) / (2.0 * rho);
                 const double en = a + sqrt(a * a + mu * rr / (2.0 * rho));
                 const double ep = rr + en;
-                W.lo[j] = lo; W.up[j] = up; W.g[j] = g; W.s[j] = s; W.p[j] = ep; W.n[j] = en;
+                W.g[j] = g; W.s[j] = s; W.p[j] = ep; W.n[j] = en;
                 W.zp[j] = mu / ep; W.zn[j] = mu / en; W.y[j] = rho - mu / ep;
                 W.zL[j] = (!eq && hasL) ? 1.0 : 0.0;
                 W.zU[j] = (!eq && hasU) ? 1.0 : 0.0;
@@ -1274,7 +1279,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
         }
         rxmax = wave_max(rxmax); crotmax = wave_max(crotmax); nusum = wave_sum(nusum); th = wave_sum(th);
         pnsum = wave_sum(pnsum); elastic_max = wave_max(emax);
-        const Err e0 = ipm_errors<RPL>(L, W, 0.0, rho, rxmax, crotmax, nusum, lane);
+        const Err e0 = ipm_errors<RPL>(L, S, W, 0.0, rho, rxmax, crotmax, nusum, lane);
         E0 = e0.E;
         if (it == 0) {
             theta_max = OBCA_THETA_MAX_FACT * fmax(1.0, th);
@@ -1292,7 +1297,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
         {
             const double mu_floor = O.tol / (OBCA_KAPPA_EPS + 1.0);
             while (mu > mu_floor) {
-                const Err em = ipm_errors<RPL>(L, W, mu, rho, rxmax, crotmax, nusum, lane);
+                const Err em = ipm_errors<RPL>(L, S, W, mu, rho, rxmax, crotmax, nusum, lane);
                 if (em.E > OBCA_KAPPA_EPS * mu) break;
                 mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, mu * sqrt(mu)));      // mu^theta_mu, theta_mu = 1.5
                 tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
@@ -1315,7 +1320,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
                 if (r < L.R) {
                     const bool eq = row_iseq(L, r);
                     const double y = W.y[j];
-                    const Lin q = row_lin(W.lo[j], W.up[j], eq, W.s[j], W.p[j], W.n[j], y, W.zL[j], W.zU[j], W.zp[j],
+                    const double lo_ = S.Lb[r], up_ = S.Ub[r];
+                    const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], y, W.zL[j], W.zU[j], W.zp[j],
                                           W.zn[j], mu, rho, delta_w);
                     const double rg = W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j];
                     const double gh = rg + q.rs * q.iDs + q.rp * q.iDp - q.rn * q.iDn;
@@ -1359,11 +1365,12 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
             const int r = lane + 64 * j;
             if (r < L.R) {
                 const bool eq = row_iseq(L, r);
-                const bool hasL = !eq && W.lo[j] > -INFINITY, hasU = !eq && W.up[j] < INFINITY;
+                const double lo_ = S.Lb[r], up_ = S.Ub[r];
+            const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
                 const double dy = S.tmp[r];
                 W.dy[j] = dy;
                 {   // cached for the line search and the update (not kept live across the factorisation)
-                    const Lin q = row_lin(W.lo[j], W.up[j], eq, W.s[j], W.p[j], W.n[j], W.y[j], W.zL[j], W.zU[j], W.zp[j],
+                    const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], W.y[j], W.zL[j], W.zU[j], W.zp[j],
                                           W.zn[j], mu, rho, delta_w);
                     W.iDs[j] = q.iDs; W.iDp[j] = q.iDp; W.iDn[j] = q.iDn; W.rs[j] = q.rs; W.rp[j] = q.rp; W.rn[j] = q.rn;
                 }
@@ -1374,13 +1381,13 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
                 const double s = W.s[j], p = W.p[j], n = W.n[j];
                 double gs = eq ? 0.0 : W.rs[j] + W.y[j];
                 if (hasL) {
-                    const double sl = s - W.lo[j], zL = W.zL[j];
+                    const double sl = s - lo_, zL = W.zL[j];
                     if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
                     const double dz = (mu - zL * ds) / sl - zL;
                     if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
                 }
                 if (hasU) {
-                    const double su = W.up[j] - s, zU = W.zU[j];
+                    const double su = up_ - s, zU = W.zU[j];
                     if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
                     const double dz = (mu + zU * ds) / su - zU;
                     if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
@@ -1391,7 +1398,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
                 const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
                 if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
                 if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
-                phi += w * row_barrier(W.lo[j], W.up[j], eq, s, p, n, mu, rho);
+                phi += w * row_barrier(lo_, up_, eq, s, p, n, mu, rho);
                 dphi += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
             }
         }
@@ -1420,12 +1427,13 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
                 if (r < L.R) {
                     const bool eq = row_iseq(L, r);
                     const double dy = W.dy[j], w = row_w(L, r);
+                    const double lo_ = S.Lb[r], up_ = S.Ub[r];
                     const double st = eq ? 0.0 : W.s[j] + alpha * (dy - W.rs[j]) * W.iDs[j];
                     const double pt = W.p[j] + alpha * (dy - W.rp[j]) * W.iDp[j];
                     const double nt = W.n[j] + alpha * (-dy - W.rn[j]) * W.iDn[j];
                     const double gt = S.tmp[r];
                     th_t += w * fabs(gt - st - pt + nt);
-                    phi_t += w * row_barrier(W.lo[j], W.up[j], eq, st, pt, nt, mu, rho);
+                    phi_t += w * row_barrier(lo_, up_, eq, st, pt, nt, mu, rho);
                 }
             }
             for (int pr = lane; pr < L.npair; pr += 64) {
@@ -1468,12 +1476,13 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
             const int r = lane + 64 * j;
             if (r < L.R) {
                 const bool eq = row_iseq(L, r);
-                const bool hasL = !eq && W.lo[j] > -INFINITY, hasU = !eq && W.up[j] < INFINITY;
+                const double lo_ = S.Lb[r], up_ = S.Ub[r];
+            const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
                 const double dy = W.dy[j];
                 const double ds = (dy - W.rs[j]) * W.iDs[j];
                 const double dp = (dy - W.rp[j]) * W.iDp[j];
                 const double dn = (-dy - W.rn[j]) * W.iDn[j];
-                const double lo = W.lo[j], up = W.up[j];
+                const double lo = lo_, up = up_;
                 const double s_old = W.s[j], p_old = W.p[j], n_old = W.n[j];
                 const double s = eq ? 0.0 : s_old + alpha * ds, p = p_old + alpha * dp, n = n_old + alpha * dn;
                 const double ks = OBCA_KAPPA_SIGMA;
