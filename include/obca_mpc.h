@@ -67,7 +67,8 @@ enum {
     OBCA_STATUS_MAXITER = -1,
     OBCA_STATUS_LINESEARCH = -2,
     OBCA_STATUS_NUMERIC = -3,
-    OBCA_STATUS_BAD_BOUNDS = -4
+    OBCA_STATUS_BAD_BOUNDS = -4,
+    OBCA_STATUS_SKIPPED = -5           /* variant[b] == 0: instance not solved, outputs untouched */
 };
 
 /* return codes */
@@ -83,7 +84,9 @@ int obca_create(const obca_dims* dims, obca_handle** out);
 void obca_destroy(obca_handle* h);
 
 /*
- * Solve B independent NLPs.  variant[b] in {4, 6, 8} selects obca_mpc4 / obca_mpc6 / obca_mpc8.
+ * Solve B independent NLPs.  variant[b] in {4, 6, 8} selects obca_mpc4 / obca_mpc6 / obca_mpc8;
+ * variant[b] == 0 skips instance b (status OBCA_STATUS_SKIPPED, outputs untouched) so that a device-side
+ * driver can mask instances without a host round trip.
  *   x0    [B,3]          current pose                     (reference x0)
  *   u0    [B,2]          previous input                   (reference u0)
  *   xref  [B,3,N+1]      reference window                 (reference xref[:, :N+1])
@@ -116,6 +119,63 @@ void obca_set_profile_buffer(obca_handle* h, double* prof);
 
 /* bytes of LDS one instance needs in the wave-per-instance kernel (> 163840: only the lane kernel runs it) */
 int64_t obca_lds_bytes(const obca_dims* dims);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Device-resident closed loop: B receding-horizon rollouts advanced in lock-step without leaving the GPU.
+ *
+ * Stands behind the body of the reference's `closedLoop.closed_loop_mpc4` loop (src/closed_loop.py:345-432):
+ * update_obstacle (:445-486), sensor (:591-629), update_reference_trajectory (:502-528), the fixed-time
+ * reference preparation (:360-374 with update_path(allAviable=1) :570-587), rebuild_lObs + obstacle_H_Represent
+ * for the moving rectangles (src/demo_setting.py:457-473, src/model_obstacle.py:37-102), the variant dispatch
+ * with the mpc6 -> mpc8 fallback (:380-398) and the state advance (:400-432).  Quirks kept: q7 (Ts overwritten
+ * after a fixed-time step), q8 (vertex lists of present obstacles are not filtered by the lidar gate), cold start
+ * every solve, stop after max_steps (30) steps.  Restriction: N_free == N_fix == N (the reference default is 6/6).
+ *
+ * Static obstacles are passed as their half-space rows (host side: obstacle_H_Represent); moving obstacles as the
+ * reference's 11-tuple [cx, cy, theta, length, width, speed, end_x, end_y, end_theta, t_start, t_end] followed by
+ * cos(theta), sin(theta) as the host evaluated them (13 doubles), so that the exact `==` branch tests of
+ * obstacle_H_Represent see the same numbers as the reference.
+ */
+#define OBCA_MAX_DYN 4
+
+typedef struct obca_rollout_dims {
+    int32_t N;                         /* horizon of both the free-time and the fixed-time problem */
+    int32_t n_static;                  /* static obstacles                                          */
+    int32_t m_static[OBCA_MAX_OBST];   /* their half-space counts                                   */
+    int32_t n_dyn;                     /* moving rectangles per rollout, 0..OBCA_MAX_DYN             */
+    int32_t path_max;                  /* padded length of the reference path                       */
+    int32_t batch;                     /* rollouts                                                  */
+    int32_t max_steps;                 /* 30 in the reference (src/closed_loop.py:431)              */
+    int32_t device;
+} obca_rollout_dims;
+
+typedef struct obca_rollouts obca_rollouts;
+
+/* rollout flags */
+enum { OBCA_RUN = 0, OBCA_DONE_GOAL = 1, OBCA_DONE_CAP = 2, OBCA_DONE_FAILED = 3 };
+
+int obca_rollouts_create(const obca_rollout_dims* dims, obca_rollouts** out);
+void obca_rollouts_destroy(obca_rollouts* r);
+
+/* (Re)start all rollouts.  Device pointers: start [B,3], goal [B,2], path [B,3,path_max] (A* reference,
+ * row-major x/y/yaw), path_len [B] int32, static_A [B,Ms,2], static_b [B,Ms], dyn [B,n_dyn,13].
+ * Ts0 = the reference's self.Ts (0.1), sense_dis = setting.senseDis (10). */
+int obca_rollouts_reset(obca_rollouts* r, const double* start, const double* goal, const double* path,
+                        const int32_t* path_len, const double* static_A, const double* static_b, const double* dyn,
+                        double Ts0, double sense_dis, const obca_params* params, void* hip_stream);
+
+/* One iteration of the loop body for every rollout still running: harness kernel, one solve launch per problem
+ * shape (variant 4 on the static obstacles; variant 6, then 8 where 6 failed, per number of sensed obstacles),
+ * state advance.  Asynchronous; no host synchronisation inside. */
+int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
+
+/* Copy state and history to caller-owned DEVICE buffers (any may be NULL): x_closed [B,max_steps+1,3],
+ * u_closed [B,max_steps,2], T_closed [B,max_steps], x_openloop [B,max_steps,3,N+1], variant_hist [B,max_steps]
+ * int32 (4/6/8 as solved, 0 = no step), iters_hist [B,max_steps] int32, dyn_hist [B,max_steps,n_dyn,4]
+ * (cx, cy, present, sensed), steps [B] int32 (successful steps), flags [B] int32. */
+int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_closed, double* T_closed, double* x_openloop,
+                       int32_t* variant_hist, int32_t* iters_hist, double* dyn_hist, int32_t* steps, int32_t* flags,
+                       void* hip_stream);
 
 const char* obca_strerror(int code);
 const char* obca_version(void);

@@ -1,0 +1,92 @@
+"""Device-resident closed loop (obca_rollouts_* of include/obca_mpc.h) against the per-rollout ``closedLoop``
+mirror of the reference's loop (src/closed_loop.py:323-443, pinned by fixtures F1-F8 in tests/test_harness.py);
+both use the HIP solver, so equal inputs give equal outputs.  Config C5 of SURVEY.md 8(d)."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-7     # fp64; device cos/sin/atan2 may differ from numpy's in the last bit and the solves amplify that
+
+
+def _mirror(setting, N, n_steps):
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
+    cl = closedLoop(setting)
+    cl.N_free = cl.N_fix = N
+    steps = 0
+    while steps < n_steps and not cl.goal_reached():
+        steps += 1
+        if not cl.step():
+            break
+    return cl
+
+
+def _compare(settings, N, n_steps):
+    import torch
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
+    dr = DeviceRollouts(pack_worlds(copy.deepcopy(settings)), N=N)
+    dr.run(n_steps)
+    out = {k: v.cpu().numpy() for k, v in dr.read().items()}
+    torch.cuda.synchronize()
+    for i, st in enumerate(settings):
+        cl = _mirror(copy.deepcopy(st), N, n_steps)
+        assert out["steps"][i] == cl.k, (i, out["steps"][i], cl.k)
+        k = cl.k
+        np.testing.assert_allclose(out["x_closed"][i, :k + 1], np.asarray(cl.x_closed)[:k + 1], rtol=0, atol=TOL)
+        if k:
+            np.testing.assert_allclose(out["u_closed"][i, :k], np.asarray(cl.u_closed), rtol=0, atol=TOL)
+            np.testing.assert_allclose(out["T_closed"][i, :k], np.asarray(cl.T_closed), rtol=0, atol=TOL)
+            np.testing.assert_allclose(out["x_openloop"][i, :k], np.asarray([x.T for x in cl.x_openLoop]), rtol=0, atol=TOL)
+    return out
+
+
+def test_demo8_on_device_follows_the_mirror():
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
+    out = _compare([problemSetting("demo8")], 6, 8)
+    v = out["variant"][0, :out["steps"][0]].tolist()
+    assert v[0] == 4 and (6 in v or 8 in v)
+
+
+def test_monte_carlo_worlds_on_device_follow_the_mirror():
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
+    out = _compare([make_world_c5(i) for i in range(6)], 5, 8)
+    assert out["steps"].sum() >= 30
+
+
+def test_closed_loop_batch_properties():
+    """C5 at a few hundred rollouts, all 30 steps: every recorded step obeys the unicycle update with the recorded
+    input and step length, starts where the previous one ended, respects bounds; bookkeeping is consistent."""
+    import torch
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
+    B = 256
+    dr = DeviceRollouts([make_world_c5(i) for i in range(B)], N=5)
+    dr.run()
+    o = {k: v.cpu().numpy() for k, v in dr.read().items()}
+    torch.cuda.synchronize()
+    steps, flags = o["steps"], o["flags"]
+    assert np.all(flags != 0)                                       # every rollout ended: goal, cap or failure
+    assert np.all(steps[flags == 2] == 30)
+    assert (flags != 3).mean() > 0.5
+    done = 0
+    for i in range(B):
+        k = steps[i]
+        x, u, T = o["x_closed"][i], o["u_closed"][i], o["T_closed"][i]
+        for j in range(k):
+            nxt = x[j] + T[j] * np.array([u[j, 0] * np.cos(x[j, 2]), u[j, 0] * np.sin(x[j, 2]), u[j, 1]])
+            assert np.max(np.abs(nxt - x[j + 1])) < 1e-6, (i, j)
+            assert np.allclose(o["x_openloop"][i, j, :, 0], x[j], atol=1e-7)
+            assert o["variant"][i, j] in (4, 6, 8)
+            done += 1
+        assert np.all(o["variant"][i, k + 1:] == 0)
+        assert np.all(np.abs(u[:k, 0]) <= 0.6 + 1e-6) and np.all(np.abs(u[:k, 1]) <= np.pi / 6 + 1e-6)
+        assert np.all((x[:k + 1, 1] > 1.0) & (x[:k + 1, 1] < 9.0))
+    assert done > 0.6 * 30 * B
+    # a second run from reset reproduces the first bit for bit
+    dr.reset()
+    dr.run()
+    o2 = dr.read()
+    torch.cuda.synchronize()
+    assert np.array_equal(o2["x_closed"].cpu().numpy(), o["x_closed"])

@@ -32,8 +32,19 @@ class ObcaParams(ctypes.Structure):
                 ("max_iter_free", ctypes.c_int32), ("max_iter_fixed", ctypes.c_int32)]
 
 
+class ObcaRolloutDims(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("n_static", ctypes.c_int32), ("m_static", ctypes.c_int32 * OBCA_MAX_OBST),
+                ("n_dyn", ctypes.c_int32), ("path_max", ctypes.c_int32), ("batch", ctypes.c_int32),
+                ("max_steps", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
 EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",
-           "obca_set_profile_buffer", "obca_set_mode")
+           "obca_set_profile_buffer", "obca_set_mode", "obca_rollouts_create", "obca_rollouts_destroy",
+           "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read")
+
+OBCA_MAX_DYN = 4
+RUN, DONE_GOAL, DONE_CAP, DONE_FAILED = 0, 1, 2, 3
+STATUS_SKIPPED = -5
 
 STATUS_OK, STATUS_ACCEPTABLE, STATUS_INFEASIBLE = 0, 1, 2
 STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NUMERIC, STATUS_BAD_BOUNDS = -1, -2, -3, -4
@@ -62,6 +73,17 @@ def load():
     lib.obca_set_profile_buffer.restype = None
     lib.obca_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.obca_set_mode.restype = ctypes.c_int
+    lib.obca_rollouts_create.argtypes = [ctypes.POINTER(ObcaRolloutDims), ctypes.POINTER(ctypes.c_void_p)]
+    lib.obca_rollouts_create.restype = ctypes.c_int
+    lib.obca_rollouts_destroy.argtypes = [ctypes.c_void_p]
+    lib.obca_rollouts_destroy.restype = None
+    lib.obca_rollouts_reset.argtypes = [ctypes.c_void_p, vp, vp, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_double,
+                                        ctypes.POINTER(ObcaParams), vp]
+    lib.obca_rollouts_reset.restype = ctypes.c_int
+    lib.obca_rollouts_step.argtypes = [ctypes.c_void_p, vp]
+    lib.obca_rollouts_step.restype = ctypes.c_int
+    lib.obca_rollouts_read.argtypes = [ctypes.c_void_p] + [vp] * 10
+    lib.obca_rollouts_read.restype = ctypes.c_int
     lib.obca_lds_bytes.argtypes = [ctypes.POINTER(ObcaDims)]
     lib.obca_lds_bytes.restype = ctypes.c_int64
     lib.obca_strerror.argtypes = [ctypes.c_int]

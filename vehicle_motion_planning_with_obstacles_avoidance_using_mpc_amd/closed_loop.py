@@ -198,6 +198,8 @@ class closedLoop:
                     if k >= 1:
                         ref_x[2, k - 1] = np.arctan2(ref_x[1, k] - ref_x[1, k - 1], ref_x[0, k] - ref_x[0, k - 1])
                 ref_x[2, N] = ref_x[2, N - 1]
+            elif type == "A_star" and getattr(self.setting, "ref_path", None) is not None:
+                ref_x = np.array(self.setting.ref_path, dtype=float)      # Monte-Carlo worlds carry their own path
             elif type == "A_star":
                 st = self.setting
                 start = (st.startPose[1], st.startPose[0])

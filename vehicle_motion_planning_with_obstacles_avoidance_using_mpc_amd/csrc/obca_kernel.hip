@@ -1083,6 +1083,10 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
     const int lane = threadIdx.x;
     const int inst = blockIdx.x;
     if (inst >= A.B) return;
+    if (A.variant[inst] == 0) {                      // masked out by the caller (device-side closed loop)
+        if (lane == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; }
+        return;
+    }
 
     // ---- layout ------------------------------------------------------------------------------------
     Lay L;

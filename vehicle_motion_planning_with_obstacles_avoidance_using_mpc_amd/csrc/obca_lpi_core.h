@@ -1281,6 +1281,7 @@ LPI_FN void bind(Sh& S, const Carve& c, double* ws, size_t stride, size_t inst, 
 
 // whole per-instance job: load inputs (instance-major C-ABI layout), solve, store outputs
 LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t inst, const int* offm) {
+    if (A.variant[inst] == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; return; }
     Lay L;
     make_layout(L, A.N, A.nO, A.M, A.variant[inst]);
     const Carve c = carve(A.N, A.nO, A.M, A.n_max, A.R_max);

@@ -1,0 +1,184 @@
+// obca_rollout.hip -- device-resident closed loop (obca_rollouts_* of include/obca_mpc.h): the harness of
+// csrc/obca_rollout_core.h as one-lane-per-rollout kernels around obca_solve_batch, everything enqueued on one
+// HIP stream, no host synchronisation inside a step.
+#include <hip/hip_runtime.h>
+#include <new>
+#include <string.h>
+#include <vector>
+#include "obca_rollout_core.h"
+
+namespace {
+
+__global__ void rollout_reset_kernel(rollout::Dev D, const double* start, const double* dyn0, double Ts0) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < D.B) rollout::reset(D, b, start, dyn0, Ts0);
+}
+__global__ void rollout_prepare_kernel(rollout::Dev D) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < D.B) rollout::prepare(D, b);
+}
+__global__ void rollout_retry_kernel(rollout::Dev D, int g) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < D.B) rollout::make_retry(D, g, b);
+}
+__global__ void rollout_finish_kernel(rollout::Dev D) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < D.B) rollout::finish(D, b);
+}
+
+}  // namespace
+
+struct obca_rollouts {
+    obca_rollout_dims dims;
+    rollout::Dev D;
+    obca_handle* solver[rollout::MAX_GROUPS];
+    obca_params params;
+    bool ready;
+    std::vector<void*> allocs;
+    // constants owned by the handle (copied at reset so the caller's buffers may go away)
+    double *goal, *path, *As, *bs;
+    int32_t* path_len;
+};
+
+namespace {
+
+template <class T>
+bool dev_alloc(obca_rollouts* r, T*& p, size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, sizeof(T) * (count ? count : 1)) != hipSuccess) return false;
+    if (hipMemset(q, 0, sizeof(T) * (count ? count : 1)) != hipSuccess) return false;
+    r->allocs.push_back(q);
+    p = static_cast<T*>(q);
+    return true;
+}
+
+}  // namespace
+
+extern "C" void obca_rollouts_destroy(obca_rollouts* r) {
+    if (!r) return;
+    for (void* p : r->allocs) (void)hipFree(p);
+    for (int g = 0; g < rollout::MAX_GROUPS; ++g)
+        if (r->solver[g]) obca_destroy(r->solver[g]);
+    delete r;
+}
+
+extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** out) {
+    if (!out) return OBCA_E_INVAL;
+    *out = nullptr;
+    if (!d || d->N < 1 || d->N > 63 || d->n_static < 1 || d->n_dyn < 0 || d->n_dyn > OBCA_MAX_DYN ||
+        d->n_static + d->n_dyn > OBCA_MAX_OBST || d->path_max < 2 || d->batch < 1 || d->max_steps < 1)
+        return OBCA_E_INVAL;
+    for (int i = 0; i < d->n_static; ++i)
+        if (d->m_static[i] < 1 || d->m_static[i] > OBCA_MAX_EDGES) return OBCA_E_INVAL;
+    obca_rollouts* r = new (std::nothrow) obca_rollouts();
+    if (!r) return OBCA_E_NOMEM;
+    r->dims = *d;
+    r->ready = false;
+    for (int g = 0; g < rollout::MAX_GROUPS; ++g) r->solver[g] = nullptr;
+    if (hipSetDevice(d->device) != hipSuccess) { delete r; return OBCA_E_HIP; }
+    rollout::Dev& D = r->D;
+    memset(&D, 0, sizeof(D));
+    D.B = d->batch; D.N = d->N; D.n_static = d->n_static; D.n_dyn = d->n_dyn; D.P = d->path_max; D.S = d->max_steps;
+    D.Ms = 0;
+    for (int i = 0; i < d->n_static; ++i) D.Ms += d->m_static[i];
+    const size_t B = d->batch, N1 = d->N + 1, N = d->N, S = d->max_steps, nd = d->n_dyn;
+    bool ok = true;
+    ok = ok && dev_alloc(r, r->goal, B * 2) && dev_alloc(r, r->path, B * 3 * D.P) && dev_alloc(r, r->path_len, B) &&
+         dev_alloc(r, r->As, B * D.Ms * 2) && dev_alloc(r, r->bs, B * D.Ms);
+    D.goal = r->goal; D.path = r->path; D.path_len = r->path_len; D.As = r->As; D.bs = r->bs;
+    ok = ok && dev_alloc(r, D.x0, B * 3) && dev_alloc(r, D.u0, B * 2) && dev_alloc(r, D.Ts, B) && dev_alloc(r, D.Ts_opt, B) &&
+         dev_alloc(r, D.xprev, B * 3 * N1) && dev_alloc(r, D.dyn, B * nd * rollout::DYN_W) && dev_alloc(r, D.k, B) &&
+         dev_alloc(r, D.flags, B) && dev_alloc(r, D.sel, B) && dev_alloc(r, D.xref, B * 3 * N1) && dev_alloc(r, D.term, B * 3);
+    ok = ok && dev_alloc(r, D.xc, B * (S + 1) * 3) && dev_alloc(r, D.uc, B * S * 2) && dev_alloc(r, D.Tc, B * S) &&
+         dev_alloc(r, D.xol, B * S * 3 * N1) && dev_alloc(r, D.dh, B * S * nd * 4) && dev_alloc(r, D.vh, B * S) &&
+         dev_alloc(r, D.ih, B * S);
+    int rc = ok ? OBCA_OK : OBCA_E_NOMEM;
+    for (int g = 0; g <= d->n_dyn && rc == OBCA_OK; ++g) {
+        const size_t Mg = D.Ms + 4 * g;
+        ok = dev_alloc(r, D.var[g], B) && dev_alloc(r, D.var8[g], B) && dev_alloc(r, D.A[g], B * N1 * Mg * 2) &&
+             dev_alloc(r, D.b[g], B * N1 * Mg) && dev_alloc(r, D.xopt[g], B * 3 * N1) && dev_alloc(r, D.uopt[g], B * 2 * N) &&
+             dev_alloc(r, D.ts[g], B) && dev_alloc(r, D.status[g], B) && dev_alloc(r, D.iters[g], B) &&
+             dev_alloc(r, D.status8[g], B) && dev_alloc(r, D.iters8[g], B);
+        if (!ok) { rc = OBCA_E_NOMEM; break; }
+        obca_dims sd;
+        memset(&sd, 0, sizeof(sd));
+        sd.N = d->N; sd.n_obs = d->n_static + g; sd.max_batch = d->batch; sd.device = d->device;
+        for (int i = 0; i < d->n_static; ++i) sd.m[i] = d->m_static[i];
+        for (int i = 0; i < g; ++i) sd.m[d->n_static + i] = 4;
+        rc = obca_create(&sd, &r->solver[g]);
+    }
+    if (rc != OBCA_OK) { obca_rollouts_destroy(r); return rc; }
+    *out = r;
+    return OBCA_OK;
+}
+
+extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const double* goal, const double* path,
+                                   const int32_t* path_len, const double* static_A, const double* static_b,
+                                   const double* dyn, double Ts0, double sense_dis, const obca_params* params,
+                                   void* hip_stream) {
+    if (!r || !start || !goal || !path || !path_len || !static_A || !static_b || !params || (r->dims.n_dyn > 0 && !dyn))
+        return OBCA_E_INVAL;
+    hipStream_t s = (hipStream_t)hip_stream;
+    rollout::Dev& D = r->D;
+    const size_t B = D.B, N1 = D.N + 1, S = D.S, nd = D.n_dyn;
+    bool ok = hipMemcpyAsync(r->goal, goal, sizeof(double) * B * 2, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(r->path, path, sizeof(double) * B * 3 * D.P, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(r->path_len, path_len, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(r->As, static_A, sizeof(double) * B * D.Ms * 2, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(r->bs, static_b, sizeof(double) * B * D.Ms, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    ok = ok && hipMemsetAsync(D.xc, 0, sizeof(double) * B * (S + 1) * 3, s) == hipSuccess &&
+         hipMemsetAsync(D.uc, 0, sizeof(double) * B * S * 2, s) == hipSuccess &&
+         hipMemsetAsync(D.Tc, 0, sizeof(double) * B * S, s) == hipSuccess &&
+         hipMemsetAsync(D.xol, 0, sizeof(double) * B * S * 3 * N1, s) == hipSuccess &&
+         hipMemsetAsync(D.dh, 0, sizeof(double) * (B * S * nd * 4 ? B * S * nd * 4 : 1), s) == hipSuccess &&
+         hipMemsetAsync(D.vh, 0, sizeof(int32_t) * B * S, s) == hipSuccess &&
+         hipMemsetAsync(D.ih, 0, sizeof(int32_t) * B * S, s) == hipSuccess;
+    if (!ok) return OBCA_E_HIP;
+    r->params = *params;
+    D.sense_dis = sense_dis;
+    D.ego_l = params->ego[0];                                  // the gate uses ego[0], ego[1] (src/closed_loop.py:594)
+    D.ego_w = params->ego[1];
+    hipLaunchKernelGGL(rollout_reset_kernel, dim3((D.B + 63) / 64), dim3(64), 0, s, D, start, dyn, Ts0);
+    if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
+    r->ready = true;
+    return OBCA_OK;
+}
+
+extern "C" int obca_rollouts_step(obca_rollouts* r, void* hip_stream) {
+    if (!r || !r->ready) return OBCA_E_INVAL;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const rollout::Dev& D = r->D;
+    const dim3 grid((D.B + 63) / 64), block(64);
+    hipLaunchKernelGGL(rollout_prepare_kernel, grid, block, 0, s, D);
+    for (int g = 0; g <= D.n_dyn; ++g) {
+        int rc = obca_solve_batch(r->solver[g], D.var[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term, &r->params,
+                                  D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr, hip_stream);
+        if (rc != OBCA_OK) return rc;
+        if (g == 0) continue;
+        hipLaunchKernelGGL(rollout_retry_kernel, grid, block, 0, s, D, g);
+        rc = obca_solve_batch(r->solver[g], D.var8[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term, &r->params,
+                              D.xopt[g], D.uopt[g], D.ts[g], D.status8[g], D.iters8[g], nullptr, hip_stream);
+        if (rc != OBCA_OK) return rc;
+    }
+    hipLaunchKernelGGL(rollout_finish_kernel, grid, block, 0, s, D);
+    if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
+    return OBCA_OK;
+}
+
+extern "C" int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_closed, double* T_closed,
+                                  double* x_openloop, int32_t* variant_hist, int32_t* iters_hist, double* dyn_hist,
+                                  int32_t* steps, int32_t* flags, void* hip_stream) {
+    if (!r || !r->ready) return OBCA_E_INVAL;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const rollout::Dev& D = r->D;
+    const size_t B = D.B, N1 = D.N + 1, S = D.S, nd = D.n_dyn;
+    auto cp = [&](void* dst, const void* src, size_t bytes) {
+        return !dst || bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    };
+    const bool ok = cp(x_closed, D.xc, sizeof(double) * B * (S + 1) * 3) && cp(u_closed, D.uc, sizeof(double) * B * S * 2) &&
+                    cp(T_closed, D.Tc, sizeof(double) * B * S) && cp(x_openloop, D.xol, sizeof(double) * B * S * 3 * N1) &&
+                    cp(variant_hist, D.vh, sizeof(int32_t) * B * S) && cp(iters_hist, D.ih, sizeof(int32_t) * B * S) &&
+                    cp(dyn_hist, D.dh, sizeof(double) * B * S * nd * 4) && cp(steps, D.k, sizeof(int32_t) * B) &&
+                    cp(flags, D.flags, sizeof(int32_t) * B);
+    return ok ? OBCA_OK : OBCA_E_HIP;
+}

@@ -79,6 +79,21 @@ class problemSetting:
         if demo_name not in _DEMOS:
             raise KeyError("unknown demo %r" % (demo_name,))
         xU, start, goal, polys, dyn, term = _DEMOS[demo_name]
+        self._setup(demo_name, xU, start, goal, polys, dyn, term)
+
+    @classmethod
+    def from_world(cls, xU, start, goal, static_lObs, static_gridlObs, dyn, terminal_set, ref_path=None,
+                   name="custom"):
+        """A setting that is not in the reference's demo table (Monte-Carlo worlds, config C5).  ``ref_path``
+        (3,P) replaces the A* reference when given."""
+        self = cls.__new__(cls)
+        self._setup(name, xU, start, goal, lambda: (static_lObs, static_gridlObs), dyn, terminal_set)
+        self.ref_path = None if ref_path is None else np.asarray(ref_path, float)
+        return self
+
+    ref_path = None
+
+    def _setup(self, demo_name, xU, start, goal, polys, dyn, term):
         self.demo_name = demo_name
         self.xL = [0, 0]
         self.xU = list(xU)

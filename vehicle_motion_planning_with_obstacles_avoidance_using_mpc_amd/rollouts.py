@@ -1,0 +1,146 @@
+"""Device-resident closed loop: B receding-horizon rollouts advanced on the GPU without host round trips.
+
+Batched counterpart of the reference's ``closedLoop.closed_loop_mpc4`` (reference src/closed_loop.py:323-443):
+``pack_worlds`` turns B ``problemSetting`` objects into the structure-of-arrays the C ABI takes
+(``obca_rollouts_*`` in include/obca_mpc.h), ``DeviceRollouts`` drives them.  The per-rollout Python class
+``closed_loop.closedLoop`` stays the readable mirror of the reference; tests compare the two step by step.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .a_star import a_star
+from .model_obstacle import obstacleModel
+from .solver import SolverParams
+
+
+class PackedWorlds:
+    """start [B,3], goal [B,2], path [B,3,P], path_len [B], static_A [B,Ms,2], static_b [B,Ms], dyn [B,nDyn,13]"""
+    __slots__ = ("m_static", "n_dyn", "start", "goal", "path", "path_len", "static_A", "static_b", "dyn", "sense_dis")
+
+    @property
+    def batch(self):
+        return self.start.shape[0]
+
+
+def reference_path(setting):
+    """the (3,P) reference the closed loop tracks: the setting's own path or the A* route (src/closed_loop.py:340)"""
+    if getattr(setting, "ref_path", None) is not None:
+        return np.asarray(setting.ref_path, float)
+    start = (setting.startPose[1], setting.startPose[0])
+    goal = (setting.goalPose[1], setting.goalPose[0])
+    planner = a_star(setting.org_gridMap, start, goal)
+    route = planner.solve(setting.org_gridMap, start, goal)
+    return np.asarray(planner.create_reference_path(planner.rebuild_path(route)), float).T
+
+
+def pack_worlds(settings, path_max=None):
+    """B settings of one shape (same static edge counts, same number of moving rectangles) -> PackedWorlds."""
+    settings = list(settings)
+    om = obstacleModel()
+    m0 = [int(v) - 1 for v in settings[0].static_vObs]
+    nd = len(settings[0].dyn_obs_info)
+    if nd > _lib.OBCA_MAX_DYN:
+        raise ValueError("at most %d moving obstacles per rollout" % _lib.OBCA_MAX_DYN)
+    paths = [reference_path(s) for s in settings]
+    P = max(p.shape[1] for p in paths) if path_max is None else int(path_max)
+    B, Ms = len(settings), sum(m0)
+    w = PackedWorlds()
+    w.m_static, w.n_dyn = m0, nd
+    w.start = np.zeros((B, 3)); w.goal = np.zeros((B, 2)); w.path = np.zeros((B, 3, P))
+    w.path_len = np.zeros(B, dtype=np.int32)
+    w.static_A = np.zeros((B, Ms, 2)); w.static_b = np.zeros((B, Ms)); w.dyn = np.zeros((B, nd, 13))
+    w.sense_dis = float(settings[0].senseDis)
+    for i, s in enumerate(settings):
+        if [int(v) - 1 for v in s.static_vObs] != m0 or len(s.dyn_obs_info) != nd or float(s.senseDis) != w.sense_dis:
+            raise ValueError("setting %d has a different shape than setting 0" % i)
+        w.start[i] = np.asarray(s.startPose[:3], float)
+        w.goal[i] = np.asarray(s.goalPose[:2], float)
+        p = paths[i]
+        w.path[i, :, :p.shape[1]] = p
+        w.path[i, :, p.shape[1]:] = p[:, -1:]
+        w.path_len[i] = p.shape[1]
+        A, b = om.obstacle_H_Represent(s.static_nObs, s.static_vObs, s.static_lObs)
+        w.static_A[i], w.static_b[i] = A, b[:, 0]
+        for j, d in enumerate(s.dyn_obs_info):
+            w.dyn[i, j, :11] = np.asarray(d[:11], float)
+            w.dyn[i, j, 11], w.dyn[i, j, 12] = np.cos(d[2]), np.sin(d[2])
+    return w
+
+
+def rollout_dims(w, N, max_steps, device=0):
+    d = _lib.ObcaRolloutDims()
+    d.N, d.n_static, d.n_dyn = int(N), len(w.m_static), int(w.n_dyn)
+    for i, v in enumerate(w.m_static):
+        d.m_static[i] = int(v)
+    d.path_max, d.batch, d.max_steps, d.device = int(w.path.shape[2]), int(w.batch), int(max_steps), int(device)
+    return d
+
+
+class DeviceRollouts:
+    """B rollouts on one GPU.  ``step()`` enqueues one receding-horizon step of every running rollout;
+    ``run()`` all of them; ``read()`` returns state and history (torch tensors on the device)."""
+
+    def __init__(self, worlds, N=5, params=None, Ts0=0.1, max_steps=30, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceRollouts needs a ROCm GPU; there is no CPU fallback on the product path")
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.w = worlds if isinstance(worlds, PackedWorlds) else pack_worlds(worlds)
+        self.N, self.max_steps, self.Ts0 = int(N), int(max_steps), float(Ts0)
+        self.params = params or SolverParams()
+        self._dims = rollout_dims(self.w, N, max_steps, self.device.index or 0)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.obca_rollouts_create(ctypes.byref(self._dims), ctypes.byref(h)))
+        self._h = h
+        self.steps_enqueued = 0
+        self.reset()
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        t, w = self.torch, self.w
+        dev = lambda a, dt: t.as_tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
+        self._inputs = [dev(w.start, t.float64), dev(w.goal, t.float64), dev(w.path, t.float64),
+                        dev(w.path_len, t.int32), dev(w.static_A, t.float64), dev(w.static_b, t.float64),
+                        dev(w.dyn if w.n_dyn else np.zeros((w.batch, 1, 13)), t.float64)]
+        self._cparams = self.params.to_c()
+        ptrs = [ctypes.c_void_p(x.data_ptr()) for x in self._inputs]
+        _lib.check(self.lib.obca_rollouts_reset(self._h, *ptrs, self.Ts0, w.sense_dis, ctypes.byref(self._cparams),
+                                                self._stream()))
+        self.steps_enqueued = 0
+
+    def step(self):
+        _lib.check(self.lib.obca_rollouts_step(self._h, self._stream()))
+        self.steps_enqueued += 1
+
+    def run(self, n_steps=None):
+        for _ in range(self.max_steps if n_steps is None else n_steps):
+            self.step()
+        return self
+
+    def read(self):
+        t, B, S, N1, nd = self.torch, self.w.batch, self.max_steps, self.N + 1, self.w.n_dyn
+        f = lambda *shape: t.empty(*shape, dtype=t.float64, device=self.device)
+        i = lambda *shape: t.empty(*shape, dtype=t.int32, device=self.device)
+        out = {"x_closed": f(B, S + 1, 3), "u_closed": f(B, S, 2), "T_closed": f(B, S), "x_openloop": f(B, S, 3, N1),
+               "variant": i(B, S), "iters": i(B, S), "dyn": f(B, S, max(nd, 1), 4), "steps": i(B), "flags": i(B)}
+        order = ("x_closed", "u_closed", "T_closed", "x_openloop", "variant", "iters", "dyn", "steps", "flags")
+        ptrs = [ctypes.c_void_p(out[k].data_ptr()) if (k != "dyn" or nd) else None for k in order]
+        _lib.check(self.lib.obca_rollouts_read(self._h, *ptrs, self._stream()))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.obca_rollouts_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -250,3 +250,55 @@ def make_batch_c3(B, N=20, first=0, gated=True):
     return dict(m=m, variant=np.full(B, var, dtype=np.int32), x0=np.stack([q["x0"] for q in ins]),
                 u0=np.stack([q["u0"] for q in ins]), xref=np.stack([q["xref"] for q in ins]), A=A, b=b, Ts=Ts,
                 term=np.stack([q["term"] for q in ins]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Config C5: closed-loop Monte-Carlo worlds -- C2 corridor with one random box and ``n_dyn`` 3x3
+# boxes crossing it; each world is a ``problemSetting`` so that the per-rollout ``closedLoop`` mirror and the
+# device-resident ``DeviceRollouts`` consume the same object.
+def _one_way_path(y0, box):
+    """lattice_path that detours upwards only and stays on the detour row: the reference's time-scale bound is a
+    SIGNED sum of the window's x and y extents (src/obca.py:961-962, quirk q3), so its free-time problem is
+    infeasible on windows that run towards smaller y -- the reference's own demos only ever climb."""
+    path = lattice_path(y0, box)
+    if path is None:
+        return None
+    y = path[1].copy()
+    if np.any(np.diff(y) < 0):
+        top = int(np.argmax(y))
+        if top == 0 or np.any(np.diff(y[:top + 1]) < 0):
+            return None                              # detour goes down first
+        y[top:] = y[top]
+        path = path.copy()
+        path[1] = y
+        for i in range(path.shape[1] - 1):
+            path[2, i] = math.atan2(path[1, i + 1] - path[1, i], path[0, i + 1] - path[0, i])
+        path[2, -1] = path[2, -2]
+    return path
+
+
+def make_world_c5(i, n_dyn=2, seed0=SEED0 + 2 * 10 ** 6):
+    from .demo_setting import problemSetting
+    rng = np.random.default_rng(seed0 + i)
+    for _ in range(200):
+        box = (rng.uniform(14, 30), rng.uniform(2.5, 7.5), rng.uniform(2, 5), rng.uniform(2, 5))
+        y0 = int(round(rng.uniform(3, 7)))
+        path = _one_way_path(y0, box)
+        dyn = []
+        for _d in range(n_dyn):
+            up = rng.uniform() < 0.5
+            cx, v = rng.uniform(10, 35), rng.uniform(0.1, 0.5)
+            th = math.pi / 2 if up else -math.pi / 2
+            dyn.append([cx, 0.0 if up else 9.0, th, 3, 3, v, cx, 9.0 if up else 0.0, th, 0, 100])
+        if path is None:
+            continue
+        start = [float(path[0, 0]), float(path[1, 0]), 0.0]
+        if clearance(np.array(start), box) < DMIN + 0.1:
+            continue
+        rect = rectangle_vertices(box[0], box[1], 0.0, box[2], box[3])
+        static = [[[39, 9], [0, 9]], rect, [[0, 1], [39, 1]]]
+        grid = [[[39, 9], [0, 9], [0, 10], [39, 10]], rect[:4], [[0, 1], [39, 1], [39, 0], [0, 0]]]
+        goal = [float(path[0, -1]), float(path[1, -1]), 0.0]
+        return problemSetting.from_world((39, 10), start, goal, static, grid, dyn, [[25, 39], [1, 9]], ref_path=path,
+                                         name="c5_%d" % i)
+    raise RuntimeError("could not draw a C5 world for seed %d" % (seed0 + i))
