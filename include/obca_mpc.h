@@ -169,6 +169,13 @@ int obca_rollouts_reset(obca_rollouts* r, const double* start, const double* goa
  * state advance.  Asynchronous; no host synchronisation inside. */
 int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
 
+/* n_steps iterations for every rollout.  Default (mode 0): when every problem shape fits the wave kernel, ONE launch
+ * of a persistent kernel in which each wavefront owns a rollout for all its steps (harness on lane 0, solves on the
+ * wave) -- rollouts then advance independently instead of in lock step, so one expensive solve does not hold the batch
+ * back; results are identical to n_steps calls of obca_rollouts_step.  Mode 1 forces the lock-step launches. */
+int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_stream);
+int obca_rollouts_set_mode(obca_rollouts* r, int mode);
+
 /* Copy state and history to caller-owned DEVICE buffers (any may be NULL): x_closed [B,max_steps+1,3],
  * u_closed [B,max_steps,2], T_closed [B,max_steps], x_openloop [B,max_steps,3,N+1], variant_hist [B,max_steps]
  * int32 (4/6/8 as solved, 0 = no step), iters_hist [B,max_steps] int32, dyn_hist [B,max_steps,n_dyn,4]

@@ -40,7 +40,8 @@ class ObcaRolloutDims(ctypes.Structure):
 
 EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",
            "obca_set_profile_buffer", "obca_set_mode", "obca_rollouts_create", "obca_rollouts_destroy",
-           "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read")
+           "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read", "obca_rollouts_run",
+           "obca_rollouts_set_mode")
 
 OBCA_MAX_DYN = 4
 RUN, DONE_GOAL, DONE_CAP, DONE_FAILED = 0, 1, 2, 3
@@ -82,6 +83,10 @@ def load():
     lib.obca_rollouts_reset.restype = ctypes.c_int
     lib.obca_rollouts_step.argtypes = [ctypes.c_void_p, vp]
     lib.obca_rollouts_step.restype = ctypes.c_int
+    lib.obca_rollouts_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, vp]
+    lib.obca_rollouts_run.restype = ctypes.c_int
+    lib.obca_rollouts_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.obca_rollouts_set_mode.restype = ctypes.c_int
     lib.obca_rollouts_read.argtypes = [ctypes.c_void_p] + [vp] * 10
     lib.obca_rollouts_read.restype = ctypes.c_int
     lib.obca_lds_bytes.argtypes = [ctypes.POINTER(ObcaDims)]

@@ -122,18 +122,17 @@ extern "C" int obca_set_mode(obca_handle* h, int mode) {
 
 extern "C" void obca_set_profile_buffer(obca_handle* h, double* prof) { if (h) h->prof = prof; }
 
-extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
-                                const double* x0, const double* u0, const double* xref,
-                                const double* A, const double* b, const double* Ts, const double* term,
-                                const obca_params* p,
-                                double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
-                                double* info, void* hip_stream) {
+int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
+                              const double* x0, const double* u0, const double* xref,
+                              const double* A, const double* b, const double* Ts, const double* term,
+                              const obca_params* p,
+                              double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
+                              double* info, ObcaLaunch* out, int64_t* lds_bytes, int* wave_ok) {
     if (!h || !variant || !x0 || !u0 || !xref || !A || !b || !Ts || !p || !xopt || !uopt || !ts_opt || !status ||
-        !iters)
+        !iters || !out)
         return OBCA_E_INVAL;
     if (B < 0 || B > h->dims.max_batch) return OBCA_E_INVAL;
-    if (B == 0) return OBCA_OK;
-    ObcaLaunch L;
+    ObcaLaunch& L = *out;
     memset(&L, 0, sizeof(L));
     L.B = B; L.N = h->dims.N; L.nO = h->dims.n_obs; L.M = h->M; L.n_max = h->n_max; L.R_max = h->R_max; L.inst_off = h->inst_off;
     for (int i = 0; i <= OBCA_MAX_OBST; ++i) L.offm[i] = h->offm[i];
@@ -164,6 +163,22 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     L.prm.opt.feas_tol = p->feas_tol > 0 ? p->feas_tol : 1e-6;
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
+    if (lds_bytes) *lds_bytes = h->lds_bytes;
+    if (wave_ok) *wave_ok = h->wave_ok ? 1 : 0;
+    return OBCA_OK;
+}
+
+extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
+                                const double* x0, const double* u0, const double* xref,
+                                const double* A, const double* b, const double* Ts, const double* term,
+                                const obca_params* p,
+                                double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
+                                double* info, void* hip_stream) {
+    ObcaLaunch L;
+    const int rc = obca_internal_fill_launch(h, variant, B, x0, u0, xref, A, b, Ts, term, p, xopt, uopt, ts_opt, status,
+                                             iters, info, &L, nullptr, nullptr);
+    if (rc != OBCA_OK) return rc;
+    if (B == 0) return OBCA_OK;
     // wave kernel (working set in LDS) whenever the shape fits one CU; the lane kernel (working set in an HBM
     // workspace, one instance per lane) takes the shapes beyond the LDS -- measured on MI355X it is latency bound
     // (every access is an L2/HBM round trip at one wave per SIMD) and 4-10x slower where both run

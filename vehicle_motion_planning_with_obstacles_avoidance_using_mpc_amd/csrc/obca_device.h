@@ -62,4 +62,13 @@ struct ObcaLaunch {
     ObcaParamsDev prm;
 };
 
+
+// internal (not part of the C ABI): the launch descriptor obca_solve_batch builds, for kernels that embed the solver
+int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
+                              const double* x0, const double* u0, const double* xref,
+                              const double* A, const double* b, const double* Ts, const double* term,
+                              const obca_params* p,
+                              double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
+                              double* info, ObcaLaunch* out, int64_t* lds_bytes, int* wave_ok);
+
 #endif

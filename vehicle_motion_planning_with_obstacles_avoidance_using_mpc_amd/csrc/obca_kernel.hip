@@ -1078,10 +1078,9 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
 
 // ================================================================== the kernel
 template <int RPL>
-__device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
+__device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int inst) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
-    const int inst = blockIdx.x;
     if (inst >= A.B) return;
     if (A.variant[inst] == 0) {                      // masked out by the caller (device-side closed loop)
         if (lane == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; }
@@ -1165,7 +1164,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
     }
     SYNC();
 
-    const ObcaOptsDev& O = A.prm.opt;
+    const ObcaOptsDev O = A.prm.opt;          // by value: A may live in HBM (fused closed-loop kernel)
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
@@ -1559,5 +1558,38 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A) {
 }
 
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A) { obca_ipm_body<4>(A); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A) { obca_ipm_body<6>(A); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A) { obca_ipm_body<4>(A, blockIdx.x); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A) { obca_ipm_body<6>(A, blockIdx.x); }
+
+// ================================================================== fused closed loop
+// One wavefront owns one rollout for its whole life: lane 0 runs the harness of csrc/obca_rollout_core.h between
+// the solves, the wave runs the solves (obca_mpc4, or obca_mpc6 and, where that fails, obca_mpc8).  Nothing is
+// shared between rollouts, so there is no lock step: a rollout that meets an expensive solve (an infeasible
+// obca_mpc6 runs to max_iter before the fallback) does not hold the others back.  `launches[g + a*MAX_GROUPS]`
+// is the descriptor obca_solve_batch would use for problem shape g (= sensed moving obstacles), a = 1 the retry.
+#include "obca_rollout_core.h"
+
+extern "C" __global__ void __launch_bounds__(64)
+obca_rollout_fused_kernel(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
+    const rollout::Dev& D = *Dp;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= D.B) return;
+    for (int step = 0; step < n_steps; ++step) {
+        if (lane == 0) rollout::prepare(D, b);
+        __syncthreads();
+        if (D.flags[b] != OBCA_RUN) break;
+        const int g = D.sel[b];
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (attempt == 1) {
+                if (g == 0) break;
+                if (lane == 0) rollout::make_retry(D, g, b);
+                __syncthreads();
+                if (D.var8[g][b] != 8) break;
+            }
+            obca_ipm_body<6>(launches[g + attempt * rollout::MAX_GROUPS], b);
+            __syncthreads();
+        }
+        if (lane == 0) rollout::finish(D, b);
+        __syncthreads();
+    }
+}

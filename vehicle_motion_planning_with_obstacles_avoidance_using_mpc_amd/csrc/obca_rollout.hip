@@ -5,7 +5,10 @@
 #include <new>
 #include <string.h>
 #include <vector>
+#include "obca_device.h"
 #include "obca_rollout_core.h"
+
+extern "C" __global__ void obca_rollout_fused_kernel(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
 
 namespace {
 
@@ -35,6 +38,16 @@ struct obca_rollouts {
     obca_params params;
     bool ready;
     std::vector<void*> allocs;
+    // the problem shapes of one step are independent: each gets its own stream, forked from / joined to the caller's
+    hipStream_t gstream[rollout::MAX_GROUPS];
+    hipEvent_t fork, join[rollout::MAX_GROUPS];
+    // fused path: descriptors in HBM for the persistent one-wave-per-rollout kernel (obca_kernel.hip)
+    rollout::Dev* dD;
+    ObcaLaunch* dL;
+    ObcaLaunch hL[2 * rollout::MAX_GROUPS];
+    bool fused_ok;
+    int64_t lds_max;
+    int mode;                 /* 0 auto (fused when every shape fits the wave kernel), 1 lock-step launches */
     // constants owned by the handle (copied at reset so the caller's buffers may go away)
     double *goal, *path, *As, *bs;
     int32_t* path_len;
@@ -57,8 +70,12 @@ bool dev_alloc(obca_rollouts* r, T*& p, size_t count) {
 extern "C" void obca_rollouts_destroy(obca_rollouts* r) {
     if (!r) return;
     for (void* p : r->allocs) (void)hipFree(p);
-    for (int g = 0; g < rollout::MAX_GROUPS; ++g)
+    for (int g = 0; g < rollout::MAX_GROUPS; ++g) {
         if (r->solver[g]) obca_destroy(r->solver[g]);
+        if (r->gstream[g]) (void)hipStreamDestroy(r->gstream[g]);
+        if (r->join[g]) (void)hipEventDestroy(r->join[g]);
+    }
+    if (r->fork) (void)hipEventDestroy(r->fork);
     delete r;
 }
 
@@ -74,7 +91,8 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     if (!r) return OBCA_E_NOMEM;
     r->dims = *d;
     r->ready = false;
-    for (int g = 0; g < rollout::MAX_GROUPS; ++g) r->solver[g] = nullptr;
+    for (int g = 0; g < rollout::MAX_GROUPS; ++g) { r->solver[g] = nullptr; r->gstream[g] = nullptr; r->join[g] = nullptr; }
+    r->fork = nullptr;
     if (hipSetDevice(d->device) != hipSuccess) { delete r; return OBCA_E_HIP; }
     rollout::Dev& D = r->D;
     memset(&D, 0, sizeof(D));
@@ -106,7 +124,14 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
         for (int i = 0; i < d->n_static; ++i) sd.m[i] = d->m_static[i];
         for (int i = 0; i < g; ++i) sd.m[d->n_static + i] = 4;
         rc = obca_create(&sd, &r->solver[g]);
+        if (rc == OBCA_OK && g > 0 &&
+            (hipStreamCreateWithFlags(&r->gstream[g], hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreateWithFlags(&r->join[g], hipEventDisableTiming) != hipSuccess))
+            rc = OBCA_E_HIP;
     }
+    if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
+    r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0;
+    if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS))) rc = OBCA_E_NOMEM;
     if (rc != OBCA_OK) { obca_rollouts_destroy(r); return rc; }
     *out = r;
     return OBCA_OK;
@@ -140,6 +165,29 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
     D.ego_w = params->ego[1];
     hipLaunchKernelGGL(rollout_reset_kernel, dim3((D.B + 63) / 64), dim3(64), 0, s, D, start, dyn, Ts0);
     if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
+    // descriptors of the fused kernel: the launch obca_solve_batch would make per shape, first attempt and retry
+    r->fused_ok = true;
+    r->lds_max = 0;
+    memset(r->hL, 0, sizeof(r->hL));
+    for (int g = 0; g <= D.n_dyn; ++g)
+        for (int a = 0; a < 2; ++a) {
+            int64_t lds = 0;
+            int wave_ok = 0;
+            const int rc = obca_internal_fill_launch(r->solver[g], a ? D.var8[g] : D.var[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g],
+                                                     D.Ts, D.term, &r->params, D.xopt[g], D.uopt[g], D.ts[g],
+                                                     a ? D.status8[g] : D.status[g], a ? D.iters8[g] : D.iters[g], nullptr,
+                                                     &r->hL[g + a * rollout::MAX_GROUPS], &lds, &wave_ok);
+            if (rc != OBCA_OK) return rc;
+            if (!wave_ok) r->fused_ok = false;
+            if (lds > r->lds_max) r->lds_max = lds;
+        }
+    if (hipMemcpyAsync(r->dD, &r->D, sizeof(rollout::Dev), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(r->dL, r->hL, sizeof(r->hL), hipMemcpyHostToDevice, s) != hipSuccess)
+        return OBCA_E_HIP;
+    if (r->fused_ok && r->lds_max > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(obca_rollout_fused_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_max) != hipSuccess)
+        return OBCA_E_HIP;
     r->ready = true;
     return OBCA_OK;
 }
@@ -150,18 +198,44 @@ extern "C" int obca_rollouts_step(obca_rollouts* r, void* hip_stream) {
     const rollout::Dev& D = r->D;
     const dim3 grid((D.B + 63) / 64), block(64);
     hipLaunchKernelGGL(rollout_prepare_kernel, grid, block, 0, s, D);
+    if (D.n_dyn > 0 && hipEventRecord(r->fork, s) != hipSuccess) return OBCA_E_HIP;
     for (int g = 0; g <= D.n_dyn; ++g) {
+        // group 0 (obca_mpc4, static obstacles) stays on the caller's stream; the fixed-time groups run beside it
+        hipStream_t gs = g == 0 ? s : r->gstream[g];
+        if (g > 0 && hipStreamWaitEvent(gs, r->fork, 0) != hipSuccess) return OBCA_E_HIP;
         int rc = obca_solve_batch(r->solver[g], D.var[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term, &r->params,
-                                  D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr, hip_stream);
+                                  D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr, (void*)gs);
         if (rc != OBCA_OK) return rc;
         if (g == 0) continue;
-        hipLaunchKernelGGL(rollout_retry_kernel, grid, block, 0, s, D, g);
+        hipLaunchKernelGGL(rollout_retry_kernel, grid, block, 0, gs, D, g);
         rc = obca_solve_batch(r->solver[g], D.var8[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term, &r->params,
-                              D.xopt[g], D.uopt[g], D.ts[g], D.status8[g], D.iters8[g], nullptr, hip_stream);
+                              D.xopt[g], D.uopt[g], D.ts[g], D.status8[g], D.iters8[g], nullptr, (void*)gs);
         if (rc != OBCA_OK) return rc;
+        if (hipEventRecord(r->join[g], gs) != hipSuccess || hipStreamWaitEvent(s, r->join[g], 0) != hipSuccess) return OBCA_E_HIP;
     }
     hipLaunchKernelGGL(rollout_finish_kernel, grid, block, 0, s, D);
     if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
+    return OBCA_OK;
+}
+
+extern "C" int obca_rollouts_set_mode(obca_rollouts* r, int mode) {
+    if (!r || mode < 0 || mode > 1) return OBCA_E_INVAL;
+    r->mode = mode;
+    return OBCA_OK;
+}
+
+extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_stream) {
+    if (!r || !r->ready || n_steps < 0) return OBCA_E_INVAL;
+    if (n_steps == 0) return OBCA_OK;
+    if (r->fused_ok && r->mode == 0) {
+        hipLaunchKernelGGL(obca_rollout_fused_kernel, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                           (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
+        return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
+    }
+    for (int i = 0; i < n_steps; ++i) {
+        const int rc = obca_rollouts_step(r, hip_stream);
+        if (rc != OBCA_OK) return rc;
+    }
     return OBCA_OK;
 }
 

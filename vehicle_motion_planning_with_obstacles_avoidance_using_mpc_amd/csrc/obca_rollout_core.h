@@ -20,7 +20,12 @@
 #define RO_FN inline
 #endif
 
-#pragma clang fp contract(off)
+// exact arithmetic inside the harness (no fused multiply-add): first statement of every function below
+#if defined(__clang__)
+#define RO_EXACT _Pragma("clang fp contract(off)")
+#else
+#define RO_EXACT /* g++: built with -ffp-contract=off */
+#endif
 
 namespace rollout {
 
@@ -50,6 +55,7 @@ struct Dev {
 
 // one polygon edge -> one row [a0 a1 | b]; branch order and exact comparisons of src/model_obstacle.py:63-89
 RO_FN void edge_row(double x1, double y1, double x2, double y2, double* a, double* bb) {
+    RO_EXACT
     if (x1 == x2) {
         if (y2 < y1) { a[0] = 1.0; a[1] = 0.0; *bb = x1; }
         else { a[0] = -1.0; a[1] = 0.0; *bb = -x1; }
@@ -68,6 +74,7 @@ RO_FN void edge_row(double x1, double y1, double x2, double y2, double* a, doubl
 
 // clockwise rectangle (src/demo_setting.py:405-429)
 RO_FN void rect_vertices(double cx, double cy, double c, double s, double length, double width, double V[4][2]) {
+    RO_EXACT
     const double l = length / 2, w = width / 2;
     V[0][0] = cx - l * c - w * s; V[0][1] = cy - l * s + w * c;
     V[1][0] = cx + l * c - w * s; V[1][1] = cy + l * s + w * c;
@@ -76,11 +83,13 @@ RO_FN void rect_vertices(double cx, double cy, double c, double s, double length
 }
 
 RO_FN bool at_goal(const Dev& D, int b) {
+    RO_EXACT
     const double dx = D.x0[3 * b] - D.goal[2 * b], dy = D.x0[3 * b + 1] - D.goal[2 * b + 1];
     return !(dx * dx + dy * dy >= 0.1);                                  // src/closed_loop.py:345
 }
 
 RO_FN void reset(const Dev& D, int b, const double* start, const double* dyn0, double Ts0) {
+    RO_EXACT
     for (int j = 0; j < 3; ++j) D.x0[3 * b + j] = start[3 * b + j];
     D.u0[2 * b] = 0.0; D.u0[2 * b + 1] = 0.0;
     D.Ts[b] = Ts0; D.Ts_opt[b] = Ts0;
@@ -93,6 +102,7 @@ RO_FN void reset(const Dev& D, int b, const double* start, const double* dyn0, d
 
 // everything before the solve; writes the solver inputs of the group the rollout falls into
 RO_FN void prepare(const Dev& D, int b) {
+    RO_EXACT
     const int N = D.N, N1 = N + 1, nd = D.n_dyn;
     for (int g = 0; g <= nd; ++g) D.var[g][b] = 0;
     if (D.flags[b] != OBCA_RUN) return;
@@ -207,11 +217,13 @@ RO_FN bool status_feasible(int st) { return st == OBCA_STATUS_OK || st == OBCA_S
 
 // between the obca_mpc6 launch and the obca_mpc8 launch of group g (:393-398)
 RO_FN void make_retry(const Dev& D, int g, int b) {
+    RO_EXACT
     D.var8[g][b] = (D.var[g][b] == 6 && !status_feasible(D.status[g][b])) ? 8 : 0;
 }
 
 // state advance (:400-432)
 RO_FN void finish(const Dev& D, int b) {
+    RO_EXACT
     if (D.flags[b] != OBCA_RUN) return;
     const int N = D.N, N1 = N + 1, g = D.sel[b], k = D.k[b];
     int st = D.status[g][b], it = D.iters[g][b], variant = (g == 0) ? 4 : 6;

@@ -23,6 +23,13 @@ class PackedWorlds:
     def batch(self):
         return self.start.shape[0]
 
+    def slice(self, lo, hi):
+        w = PackedWorlds()
+        w.m_static, w.n_dyn, w.sense_dis = self.m_static, self.n_dyn, self.sense_dis
+        for k in ("start", "goal", "path", "path_len", "static_A", "static_b", "dyn"):
+            setattr(w, k, getattr(self, k)[lo:hi])
+        return w
+
 
 def reference_path(setting):
     """the (3,P) reference the closed loop tracks: the setting's own path or the A* route (src/closed_loop.py:340)"""
@@ -78,6 +85,48 @@ def rollout_dims(w, N, max_steps, device=0):
     return d
 
 
+class RolloutCohorts:
+    """The batch cut into ``cohorts`` independent lock-step groups, each on its own HIP stream.  One step of a
+    group lasts as long as its slowest solve (an infeasible obca_mpc6 runs to max_iter = 1000 before the obca_mpc8
+    retry, exactly like the reference); with several groups in flight the GPU works on the others meanwhile.
+    Rollouts are independent, so the results do not depend on the cut."""
+
+    def __init__(self, worlds, cohorts=8, **kw):
+        import torch
+        self.torch = torch
+        w = worlds if isinstance(worlds, PackedWorlds) else pack_worlds(worlds)
+        B = w.batch
+        cohorts = max(1, min(int(cohorts), B))
+        cuts = [B * i // cohorts for i in range(cohorts + 1)]
+        self.streams = [torch.cuda.Stream() for _ in range(cohorts)]
+        self.parts = []
+        for i in range(cohorts):
+            with torch.cuda.stream(self.streams[i]):
+                self.parts.append(DeviceRollouts(w.slice(cuts[i], cuts[i + 1]), **kw))
+        self.max_steps = self.parts[0].max_steps
+
+    def _each(self, fn):
+        res = []
+        for st, p in zip(self.streams, self.parts):
+            with self.torch.cuda.stream(st):
+                res.append(fn(p))
+        return res
+
+    def reset(self):
+        self._each(lambda p: p.reset())
+
+    def run(self, n_steps=None):
+        for _ in range(self.max_steps if n_steps is None else n_steps):
+            self._each(lambda p: p.step())
+        return self
+
+    def read(self):
+        outs = self._each(lambda p: p.read())
+        for st in self.streams:
+            st.synchronize()
+        return {k: self.torch.cat([o[k] for o in outs]) for k in outs[0]}
+
+
 class DeviceRollouts:
     """B rollouts on one GPU.  ``step()`` enqueues one receding-horizon step of every running rollout;
     ``run()`` all of them; ``read()`` returns state and history (torch tensors on the device)."""
@@ -119,9 +168,15 @@ class DeviceRollouts:
         self.steps_enqueued += 1
 
     def run(self, n_steps=None):
-        for _ in range(self.max_steps if n_steps is None else n_steps):
-            self.step()
+        """all steps; one persistent-kernel launch when every shape fits the wave kernel (see obca_rollouts_run)"""
+        n = self.max_steps if n_steps is None else int(n_steps)
+        _lib.check(self.lib.obca_rollouts_run(self._h, n, self._stream()))
+        self.steps_enqueued += n
         return self
+
+    def set_mode(self, mode):
+        """'fused' (default where it fits) | 'lockstep' (one launch per problem shape and step)"""
+        _lib.check(self.lib.obca_rollouts_set_mode(self._h, {"fused": 0, "lockstep": 1}.get(mode, mode)))
 
     def read(self):
         t, B, S, N1, nd = self.torch, self.w.batch, self.max_steps, self.N + 1, self.w.n_dyn
