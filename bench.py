@@ -72,6 +72,32 @@ def cpu_baseline(batch, N, seconds=20.0):
             "sample": "%d instances of the same batch, numpy dense restatement (oracle/ipm_dense.py), %.1f s" % (n, dt)}
 
 
+def closed_loop_c5(B, n_dyn=2):
+    """Config C5: B Monte-Carlo rollouts of the receding-horizon loop, harness and solves on the device
+    (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds resident in HBM before the clock starts."""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
+    w = pack_worlds([sc.make_world_c5(i, n_dyn=n_dyn) for i in range(B)])
+    dr = DeviceRollouts(w, N=5)
+    dr.run(1)
+    torch.cuda.synchronize()
+    dr.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dr.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    o = {k: v.cpu().numpy() for k, v in dr.read().items()}
+    ok, tried = int(o["steps"].sum()), int((o["variant"] > 0).sum())
+    return {"workload": "C5 (SURVEY 8d): %d closed-loop rollouts, N=5, walls + random box + %d moving 3x3 boxes (lidar gate 10 m), "
+                        "<=30 steps each, obca_mpc4 / obca_mpc6 -> obca_mpc8 as the reference dispatches them" % (B, n_dyn),
+            "value": ok / dt, "unit": "converged closed-loop MPC steps/s", "seconds": dt, "converged_steps": ok,
+            "attempted_steps": tried, "rollouts_to_step_cap": int((o["flags"] == 2).sum()),
+            "rollouts_stopped_infeasible": int((o["flags"] == 3).sum()),
+            "solves_by_variant": {str(v): int((o["variant"] == v).sum()) for v in (4, 6, 8)},
+            "mean_ipm_iters": float(o["iters"][o["variant"] > 0].mean())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +108,8 @@ def main():
     ap.add_argument("--three-boxes", action="store_true", help="M=12 sub-config (3 boxes) instead of walls+box (M=6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--closed-loop-rollouts", type=int, default=4096,
+                    help="config C5 reported beside the headline number at N=1 (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +176,7 @@ def main():
     total = B * world
 
     if rank == 0:
-        value = total * args.steps / elapsed
+        value = n_ok * args.steps / elapsed             # instance-steps solved to converged/acceptable per second
         ab = alg_bytes(N, M)
         achieved = ab * B / (kern_ms * 1e-3) / 1e9
         line = {
@@ -161,7 +189,7 @@ def main():
                                    % (M, sc.SEED0),
                        "batch_per_gpu": B, "horizon_N": N, "obstacles": 3, "variant": "obca_mpc4",
                        "parallelism": "shard%d" % world},
-            "success_rate": n_ok / total, "mean_ipm_iters": it_sum / total, "mean_kkt_factorisations": nf_sum / total,
+            "attempted_steps_per_s": total * args.steps / elapsed, "success_rate": n_ok / total, "mean_ipm_iters": it_sum / total, "mean_kkt_factorisations": nf_sum / total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          # HBM bytes per launch from the PMC passes committed under profiles/ (r01d: FETCH_SIZE x2 + WRITE_SIZE)
@@ -174,6 +202,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
+        if world == 1 and args.closed_loop_rollouts > 0:
+            line["closed_loop"] = closed_loop_c5(args.closed_loop_rollouts)
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

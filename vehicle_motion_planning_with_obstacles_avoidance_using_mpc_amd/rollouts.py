@@ -116,8 +116,12 @@ class RolloutCohorts:
         self._each(lambda p: p.reset())
 
     def run(self, n_steps=None):
-        for _ in range(self.max_steps if n_steps is None else n_steps):
-            self._each(lambda p: p.step())
+        n = self.max_steps if n_steps is None else int(n_steps)
+        if all(p.mode == 0 for p in self.parts):
+            self._each(lambda p: p.run(n))                  # fused kernels: one launch per cohort
+        else:
+            for _ in range(n):
+                self._each(lambda p: p.step())
         return self
 
     def read(self):
@@ -146,6 +150,7 @@ class DeviceRollouts:
         _lib.check(self.lib.obca_rollouts_create(ctypes.byref(self._dims), ctypes.byref(h)))
         self._h = h
         self.steps_enqueued = 0
+        self.mode = 0
         self.reset()
 
     def _stream(self):
@@ -176,7 +181,8 @@ class DeviceRollouts:
 
     def set_mode(self, mode):
         """'fused' (default where it fits) | 'lockstep' (one launch per problem shape and step)"""
-        _lib.check(self.lib.obca_rollouts_set_mode(self._h, {"fused": 0, "lockstep": 1}.get(mode, mode)))
+        self.mode = {"fused": 0, "lockstep": 1}.get(mode, mode)
+        _lib.check(self.lib.obca_rollouts_set_mode(self._h, self.mode))
 
     def read(self):
         t, B, S, N1, nd = self.torch, self.w.batch, self.max_steps, self.N + 1, self.w.n_dyn
