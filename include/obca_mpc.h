@@ -184,6 +184,23 @@ int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_closed, dou
                        int32_t* variant_hist, int32_t* iters_hist, double* dyn_hist, int32_t* steps, int32_t* flags,
                        void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Batched global planner: the reference's grid A* (src/a_star.py:16-102: 8-connected, Euclidean cost and
+ * heuristic, open list ordered by (f, (row, col)), its neighbour order and re-queue rules) followed by
+ * rebuild_path (:137-147) and create_reference_path (:189-200), one rollout per GPU lane.
+ *   grid  [B,rows,cols] uint8, 1 = occupied (setting.org_gridMap);  start, goal [B,2] int32 as (row, col)
+ *         = (pose_y, pose_x) like the reference's call (src/closed_loop.py:28-30);  rows*cols <= 65535
+ *   yaw9  HOST pointer, 9 doubles: arctan2(dy, dx) for dy, dx in {-1,0,1} at index (dy+1)*3+(dx+1), as the
+ *         caller's libm evaluates them (the reference uses numpy's)
+ *   path  [B,3,path_max] x / y / yaw rows, padded with the last point; path_len [B]: points, or
+ *         -1 no route, -2 open list overflow, -3 path_max too small
+ *   workspace: device buffer of obca_astar_workspace_bytes(B, rows, cols) bytes.
+ * path / path_len are what obca_rollouts_reset takes. */
+int64_t obca_astar_workspace_bytes(int32_t B, int32_t rows, int32_t cols);
+int obca_astar_batch(const uint8_t* grid, int32_t B, int32_t rows, int32_t cols, const int32_t* start,
+                     const int32_t* goal, const double* yaw9, int32_t path_max, double* path, int32_t* path_len,
+                     void* workspace, int64_t workspace_bytes, void* hip_stream);
+
 const char* obca_strerror(int code);
 const char* obca_version(void);
 

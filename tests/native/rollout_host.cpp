@@ -59,3 +59,16 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
     for (int b = 0; b < D.B; ++b) { steps[b] = D.k[b]; flags[b] = D.flags[b]; }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// CPU exercise of the global-planner core (csrc/obca_astar_core.h), same source as the device kernel.
+#include "../../vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd/csrc/obca_astar_core.h"
+
+extern "C" int astar_host_batch(const unsigned char* grid, int B, int rows, int cols, const int* start, const int* goal,
+                                const double* yaw9, int path_max, double* path, int* path_len) {
+    std::vector<unsigned char> work(astar::work_bytes(rows * cols));
+    for (int b = 0; b < B; ++b)
+        path_len[b] = astar::plan(grid + (size_t)b * rows * cols, rows, cols, start[2 * b], start[2 * b + 1], goal[2 * b],
+                                  goal[2 * b + 1], work.data(), yaw9, path + (size_t)b * 3 * path_max, path_max);
+    return 0;
+}

@@ -42,15 +42,35 @@ def reference_path(setting):
     return np.asarray(planner.create_reference_path(planner.rebuild_path(route)), float).T
 
 
-def pack_worlds(settings, path_max=None):
-    """B settings of one shape (same static edge counts, same number of moving rectangles) -> PackedWorlds."""
+def device_reference_paths(settings):
+    """the A* references of all settings in one GPU launch (planner.plan_batch); settings that carry their own
+    ``ref_path`` keep it.  Grids must share one shape."""
+    from .planner import plan_batch
+    todo = [i for i, s in enumerate(settings) if getattr(s, "ref_path", None) is None]
+    paths = [None if i in todo else np.asarray(s.ref_path, float) for i, s in enumerate(settings)]
+    if todo:
+        grids = np.stack([np.asarray(settings[i].org_gridMap) for i in todo]).astype(np.uint8)
+        starts = [(settings[i].startPose[1], settings[i].startPose[0]) for i in todo]
+        goals = [(settings[i].goalPose[1], settings[i].goalPose[0]) for i in todo]
+        path, plen = plan_batch(grids, starts, goals)
+        path, plen = path.cpu().numpy(), plen.cpu().numpy()
+        for j, i in enumerate(todo):
+            if plen[j] < 1:
+                raise RuntimeError("no A* route for setting %d (code %d)" % (i, plen[j]))
+            paths[i] = path[j, :, :plen[j]].copy()
+    return paths
+
+
+def pack_worlds(settings, path_max=None, planner="host"):
+    """B settings of one shape (same static edge counts, same number of moving rectangles) -> PackedWorlds.
+    planner: "host" = the per-setting Python A* mirror, "device" = one batched GPU search."""
     settings = list(settings)
     om = obstacleModel()
     m0 = [int(v) - 1 for v in settings[0].static_vObs]
     nd = len(settings[0].dyn_obs_info)
     if nd > _lib.OBCA_MAX_DYN:
         raise ValueError("at most %d moving obstacles per rollout" % _lib.OBCA_MAX_DYN)
-    paths = [reference_path(s) for s in settings]
+    paths = device_reference_paths(settings) if planner == "device" else [reference_path(s) for s in settings]
     P = max(p.shape[1] for p in paths) if path_max is None else int(path_max)
     B, Ms = len(settings), sum(m0)
     w = PackedWorlds()
