@@ -116,7 +116,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:        # under torchrun the RCCL path runs even at world size 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -192,8 +192,8 @@ def main():
             "attempted_steps_per_s": total * args.steps / elapsed, "success_rate": n_ok / total, "mean_ipm_iters": it_sum / total, "mean_kkt_factorisations": nf_sum / total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         # HBM bytes per launch from the PMC passes committed under profiles/ (r01d: FETCH_SIZE x2 + WRITE_SIZE)
-                         "traffic": 14.1e6 if (B, N, M) == (8192, 5, 6) else None,
+                         # HBM bytes per launch from the PMC passes committed under profiles/ (r01e: FETCH_SIZE x2 + WRITE_SIZE)
+                         "traffic": 14.05e6 if (B, N, M) == (8192, 5, 6) else None,
                          "kernel": "obca_ipm_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_instance": ab,
                          "fp64_model_frac": value / world * (nf_sum / total) * (N + 1) * (32 ** 3 / 3 + 2 * 32 ** 2) / 78.6e12
                          if M == 6 else None,
