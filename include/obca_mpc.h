@@ -178,11 +178,12 @@ int obca_rollouts_set_mode(obca_rollouts* r, int mode);
 
 /* Copy state and history to caller-owned DEVICE buffers (any may be NULL): x_closed [B,max_steps+1,3],
  * u_closed [B,max_steps,2], T_closed [B,max_steps], x_openloop [B,max_steps,3,N+1], variant_hist [B,max_steps]
- * int32 (4/6/8 as solved, 0 = no step), iters_hist [B,max_steps] int32, dyn_hist [B,max_steps,n_dyn,4]
+ * int32 (4/6/8 as solved, 0 = no step), iters_hist [B,max_steps] int32, status_hist [B,max_steps] int32 (solver
+ * status of the step's last solve), dyn_hist [B,max_steps,n_dyn,4]
  * (cx, cy, present, sensed), steps [B] int32 (successful steps), flags [B] int32. */
 int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_closed, double* T_closed, double* x_openloop,
-                       int32_t* variant_hist, int32_t* iters_hist, double* dyn_hist, int32_t* steps, int32_t* flags,
-                       void* hip_stream);
+                       int32_t* variant_hist, int32_t* iters_hist, int32_t* status_hist, double* dyn_hist, int32_t* steps,
+                       int32_t* flags, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Batched global planner: the reference's grid A* (src/a_star.py:16-102: 8-connected, Euclidean cost and

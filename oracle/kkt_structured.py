@@ -13,8 +13,10 @@ in two levels:
   2. a backward Riccati sweep over the augmented stage state xi_k = (dp_k, du_{k-1}, dT) with input du_k,
      where the elastic dynamics rows enter through P~ = (P^-1 + E)^-1 evaluated as (I + P E)^-1 P
      (no subtraction of large numbers), followed by a forward sweep.
-Every pivot's sign is recorded; the step is accepted only if all of them are the expected sign
-(equivalent, by inertia additivity, to IPOPT's inertia test on the augmented system).
+The step is accepted only if the pivots show IPOPT's inertia for the augmented system (inertia additivity):
+each local block must have exactly two negative pivots (counted, not tested by position: an indefinite
+(lambda, mu) block that is positive definite on the null space of its rotation rows gives one negative primal
+and one positive dual pivot), every (I + P E) pivot, input-block pivot and the time-scale pivot must be positive.
 """
 import numpy as np
 
@@ -106,7 +108,7 @@ def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_i
             G[nw:] = Jrot[r:r + 2][:, ipk:ipk + 3]
             rloc = np.concatenate([-b[idx], -crot[r:r + 2]])
             L, d = ldl_nopivot(Kloc)
-            if np.any(d[:nw] <= 0) or np.any(d[nw:] >= 0):
+            if np.any(d == 0) or np.sum(d < 0) != 2:        # inertia by count (Sylvester), not by position
                 ok = False
             Y = ldl_solve(L, d, np.column_stack([G, rloc]))
             Hpp[k] -= G.T @ Y[:, :3]

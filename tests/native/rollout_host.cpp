@@ -9,7 +9,7 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
                                 const int* path_len, const double* As, const double* bs, const double* dyn, double Ts0,
                                 double sense_dis, const HostParams* hp, int n_steps,
                                 double* x_closed, double* u_closed, double* T_closed, double* x_openloop,
-                                int* variant_hist, int* iters_hist, double* dyn_hist, int* steps, int* flags,
+                                int* variant_hist, int* iters_hist, int* status_hist, double* dyn_hist, int* steps, int* flags,
                                 double* xref_hist /* [B,S,3,N+1] solver reference of every step, may be NULL */) {
     using namespace rollout;
     Dev D;
@@ -26,7 +26,7 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
     D.goal = goal; D.path = path; D.path_len = path_len; D.As = As; D.bs = bs;
     D.x0 = da(B * 3); D.u0 = da(B * 2); D.Ts = da(B); D.Ts_opt = da(B); D.xprev = da(B * 3 * N1); D.dyn = da(B * nd * DYN_W);
     D.k = ia(B); D.flags = ia(B); D.sel = ia(B); D.xref = da(B * 3 * N1); D.term = da(B * 3);
-    D.xc = x_closed; D.uc = u_closed; D.Tc = T_closed; D.xol = x_openloop; D.dh = dyn_hist; D.vh = variant_hist; D.ih = iters_hist;
+    D.xc = x_closed; D.uc = u_closed; D.Tc = T_closed; D.xol = x_openloop; D.dh = dyn_hist; D.vh = variant_hist; D.ih = iters_hist; D.sh = status_hist;
     for (int g = 0; g <= D.n_dyn; ++g) {
         const size_t Mg = D.Ms + 4 * g;
         D.var[g] = ia(B); D.var8[g] = ia(B); D.A[g] = da(B * N1 * Mg * 2); D.b[g] = da(B * N1 * Mg);

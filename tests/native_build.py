@@ -75,8 +75,8 @@ class LpiObca:
             kw.update(Qx=Q, Px=P, R1x=R[0], R2x=R[1])
         o = lpi_solve(variant, N, m, x0a[None], u0a[None], xr[None], A[None], b[None], [ts], tm[None],
                       c_oracle.default_params(**kw))
-        self.calls.append(dict(variant=variant, xref=xr.copy(), A=A.copy(), b=b.copy(), Ts=ts, term=tm.copy(), m=m,
-                               status=int(o["status"][0])))
+        self.calls.append(dict(variant=variant, x0=x0a.copy(), u0=u0a.copy(), xref=xr.copy(), A=A.copy(), b=b.copy(), Ts=ts, term=tm.copy(), m=m,
+                               status=int(o["status"][0]), info=o["info"][0].copy(), iters=int(o["iters"][0])))
         return o["xopt"][0], o["uopt"][0], bool(o["status"][0] in (0, 1)), float(o["ts_opt"][0])
 
     def obca_mpc4(self, *a):
@@ -97,7 +97,7 @@ def rollout_run(w, N, params, n_steps, max_steps=30, Ts0=0.1):
     B, S, N1, nd = w.batch, max_steps, N + 1, w.n_dyn
     out = {"x_closed": np.zeros((B, S + 1, 3)), "u_closed": np.zeros((B, S, 2)), "T_closed": np.zeros((B, S)),
            "x_openloop": np.zeros((B, S, 3, N1)), "variant": np.zeros((B, S), np.int32), "iters": np.zeros((B, S), np.int32),
-           "dyn": np.zeros((B, S, max(nd, 1), 4)), "steps": np.zeros(B, np.int32), "flags": np.zeros(B, np.int32),
+           "status": np.zeros((B, S), np.int32), "dyn": np.zeros((B, S, max(nd, 1), 4)), "steps": np.zeros(B, np.int32), "flags": np.zeros(B, np.int32),
            "xref": np.zeros((B, S, 3, N1))}
     dyn = np.ascontiguousarray(w.dyn if nd else np.zeros((B, 1, 13)))
     ins = [np.ascontiguousarray(a) for a in (w.start, w.goal, w.path)] + [np.ascontiguousarray(w.path_len, np.int32)] + \
@@ -105,7 +105,7 @@ def rollout_run(w, N, params, n_steps, max_steps=30, Ts0=0.1):
     rc = lib.rollout_host_run(ctypes.byref(d), *[_ptr(a) for a in ins], ctypes.c_double(Ts0), ctypes.c_double(w.sense_dis),
                               ctypes.byref(params), ctypes.c_int(n_steps),
                               *[_ptr(out[k]) for k in ("x_closed", "u_closed", "T_closed", "x_openloop", "variant", "iters",
-                                                       "dyn", "steps", "flags", "xref")])
+                                                       "status", "dyn", "steps", "flags", "xref")])
     assert rc == 0, rc
     return out
 

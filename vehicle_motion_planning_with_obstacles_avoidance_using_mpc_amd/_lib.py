@@ -92,7 +92,7 @@ def load():
     lib.obca_astar_batch.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp,
                                      ctypes.POINTER(ctypes.c_double), ctypes.c_int32, vp, vp, vp, ctypes.c_int64, vp]
     lib.obca_astar_batch.restype = ctypes.c_int
-    lib.obca_rollouts_read.argtypes = [ctypes.c_void_p] + [vp] * 10
+    lib.obca_rollouts_read.argtypes = [ctypes.c_void_p] + [vp] * 11
     lib.obca_rollouts_read.restype = ctypes.c_int
     lib.obca_lds_bytes.argtypes = [ctypes.POINTER(ObcaDims)]
     lib.obca_lds_bytes.restype = ctypes.c_int64

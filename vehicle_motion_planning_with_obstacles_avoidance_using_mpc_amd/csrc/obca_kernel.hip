@@ -722,11 +722,13 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
         // LDL^T without pivoting (quasi-definite when the primal block is positive definite), forward substitution
         // fused.  Rectangular constant-trip loops with predicates: after full unrolling every index is a literal,
         // so K and Yv live in registers (triangular bounds defeat the unroller and force them to scratch).
+        // Inertia: the block has NW positive and 2 negative eigenvalues iff exactly 2 of its pivots are negative
+        // (Sylvester) -- counted, not tested by position: an indefinite (lambda, mu) block that is positive definite on
+        // the null space of the rotation rows gives one negative primal and one positive dual pivot and is fine.
         double dinv[MW];
 #pragma unroll
         for (int j = 0; j < MW; ++j) {
             const double d = KP(j, j);
-            if (j < NW ? !(d > 0.0) : !(d < 0.0)) bad = 1;
             dinv[j] = 1.0 / d;
 #pragma unroll
             for (int a = 0; a < MW; ++a) {
@@ -745,6 +747,15 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
                     Yv[a][1] -= KP(a, j) * Yv[j][1];
                 }
             }
+        }
+        {
+            int nneg = 0;                       // read off the reciprocals that the back substitution keeps anyway
+#pragma unroll
+            for (int j = 0; j < MW; ++j) {
+                nneg += dinv[j] < 0.0 ? 1 : 0;
+                if (!(fabs(dinv[j]) < INFINITY)) bad = 1;          // zero or NaN pivot
+            }
+            if (nneg != 2) bad = 1;
         }
 #pragma unroll
         for (int jj = 0; jj < MW; ++jj) {

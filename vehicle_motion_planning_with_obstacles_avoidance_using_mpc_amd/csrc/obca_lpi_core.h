@@ -25,6 +25,13 @@
 #define LPI_HD static inline
 #endif
 
+#if defined(LPI_TRACE) && !defined(__HIPCC__)
+#include <stdio.h>
+#define LPI_TRACE_LINE(...) printf(__VA_ARGS__)          /* host debugging aid: one line per accepted iteration */
+#else
+#define LPI_TRACE_LINE(...)
+#endif
+
 namespace lpi {
 
 constexpr int MW = OBCA_MAX_EDGES + 6;
@@ -567,7 +574,7 @@ LPI_FN int inv3_ipe(const double* P, int ld, const double* E, double Mi[9]) {
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        if (!(A[3 * j + j] > 0.0)) bad = 1;
+        if (!(A[3 * j + j] > 0.0)) { bad = 1; LPI_TRACE_LINE("    (I+PE) pivot %d = %.3e\n", j, A[3 * j + j]); }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (i > j) {
@@ -705,10 +712,13 @@ LPI_FN int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw) {
 #pragma unroll
         for (int a = 0; a < MW; ++a) { Yv[a][0] = Gm[a][0]; Yv[a][1] = Gm[a][1]; Yv[a][2] = Gm[a][2]; }
         double dinv[MW];
+        int nneg = 0;
 #pragma unroll
         for (int j = 0; j < MW; ++j) {
             const double d = KP(j, j);
-            if (j < NW ? !(d > 0.0) : !(d < 0.0)) bad = 1;
+            // inertia by COUNT (exactly 2 negative pivots), not by position -- see csrc/obca_kernel.hip
+            if (d < 0.0) ++nneg; else if (!(d > 0.0)) bad = 1;
+            if (j == MW - 1 && nneg != 2) { bad = 1; LPI_TRACE_LINE("    pair %d: %d negative pivots\n", pr, nneg); }
             dinv[j] = 1.0 / d;
 #pragma unroll
             for (int a = 0; a < MW; ++a) {
@@ -829,7 +839,7 @@ LPI_FN int riccati(const Lay& L, const Sh& S, const Inst& in) {
         mall[7] = lk[7] + zv[4] + h * zv[2];
         const double m00 = Mall[6][6], m01 = 0.5 * (Mall[6][7] + Mall[7][6]), m11 = Mall[7][7];
         const double d1 = m11 - m01 * m01 / m00;
-        if (!(m00 > 0.0) || !(d1 > 0.0)) bad = 1;
+        if (!(m00 > 0.0) || !(d1 > 0.0)) { bad = 1; LPI_TRACE_LINE("    input block stage %d: m00 %.3e d1 %.3e\n", k, m00, d1); }
         const double idet = 1.0 / (m00 * d1);
         const double i00 = m11 * idet, i01 = -m01 * idet, i11 = m00 * idet;
         double xu[6][2], Kg[2][6];
@@ -856,7 +866,7 @@ LPI_FN int riccati(const Lay& L, const Sh& S, const Inst& in) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) { E0[j] = 1.0 / S.Einv[L.r_init + j]; g0[j] = S.gh[L.r_init + j]; }
     bad |= soft_min_regs(S.Pk, S.qk, E0, X, qt, Mi0);
-    if (L.free_T && !(X[35] > 0.0)) bad = 1;
+    if (L.free_T && !(X[35] > 0.0)) { bad = 1; LPI_TRACE_LINE("    T pivot %.3e\n", X[35]); }
     if (bad) return 1;
     // forward pass
     double dT = 0.0;
@@ -1190,6 +1200,8 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
             alpha *= 0.5;
             if (alpha < alpha_min) break;
         }
+        LPI_TRACE_LINE("it %3d th %.2e phi %.6e dphi %.2e mu %.1e dw %.1e a %.2e nfact %d nfilt %d\n", it, th, phi, dphi, mu,
+                       delta_w, accepted ? alpha : -1.0, o.nfact, nfilt);
         if (!accepted) { o.status = OBCA_STATUS_LINESEARCH; break; }
         if (aug) {
             const double tn = (1.0 - OBCA_GAMMA_THETA) * th, pn = phi - OBCA_GAMMA_PHI * th;

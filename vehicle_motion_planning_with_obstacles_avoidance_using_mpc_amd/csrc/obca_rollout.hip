@@ -109,7 +109,7 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
          dev_alloc(r, D.flags, B) && dev_alloc(r, D.sel, B) && dev_alloc(r, D.xref, B * 3 * N1) && dev_alloc(r, D.term, B * 3);
     ok = ok && dev_alloc(r, D.xc, B * (S + 1) * 3) && dev_alloc(r, D.uc, B * S * 2) && dev_alloc(r, D.Tc, B * S) &&
          dev_alloc(r, D.xol, B * S * 3 * N1) && dev_alloc(r, D.dh, B * S * nd * 4) && dev_alloc(r, D.vh, B * S) &&
-         dev_alloc(r, D.ih, B * S);
+         dev_alloc(r, D.ih, B * S) && dev_alloc(r, D.sh, B * S);
     int rc = ok ? OBCA_OK : OBCA_E_NOMEM;
     for (int g = 0; g <= d->n_dyn && rc == OBCA_OK; ++g) {
         const size_t Mg = D.Ms + 4 * g;
@@ -157,7 +157,8 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
          hipMemsetAsync(D.xol, 0, sizeof(double) * B * S * 3 * N1, s) == hipSuccess &&
          hipMemsetAsync(D.dh, 0, sizeof(double) * (B * S * nd * 4 ? B * S * nd * 4 : 1), s) == hipSuccess &&
          hipMemsetAsync(D.vh, 0, sizeof(int32_t) * B * S, s) == hipSuccess &&
-         hipMemsetAsync(D.ih, 0, sizeof(int32_t) * B * S, s) == hipSuccess;
+         hipMemsetAsync(D.ih, 0, sizeof(int32_t) * B * S, s) == hipSuccess &&
+         hipMemsetAsync(D.sh, 0, sizeof(int32_t) * B * S, s) == hipSuccess;
     if (!ok) return OBCA_E_HIP;
     r->params = *params;
     D.sense_dis = sense_dis;
@@ -240,8 +241,8 @@ extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_st
 }
 
 extern "C" int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_closed, double* T_closed,
-                                  double* x_openloop, int32_t* variant_hist, int32_t* iters_hist, double* dyn_hist,
-                                  int32_t* steps, int32_t* flags, void* hip_stream) {
+                                  double* x_openloop, int32_t* variant_hist, int32_t* iters_hist, int32_t* status_hist,
+                                  double* dyn_hist, int32_t* steps, int32_t* flags, void* hip_stream) {
     if (!r || !r->ready) return OBCA_E_INVAL;
     hipStream_t s = (hipStream_t)hip_stream;
     const rollout::Dev& D = r->D;
@@ -251,7 +252,7 @@ extern "C" int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_
     };
     const bool ok = cp(x_closed, D.xc, sizeof(double) * B * (S + 1) * 3) && cp(u_closed, D.uc, sizeof(double) * B * S * 2) &&
                     cp(T_closed, D.Tc, sizeof(double) * B * S) && cp(x_openloop, D.xol, sizeof(double) * B * S * 3 * N1) &&
-                    cp(variant_hist, D.vh, sizeof(int32_t) * B * S) && cp(iters_hist, D.ih, sizeof(int32_t) * B * S) &&
+                    cp(variant_hist, D.vh, sizeof(int32_t) * B * S) && cp(iters_hist, D.ih, sizeof(int32_t) * B * S) && cp(status_hist, D.sh, sizeof(int32_t) * B * S) &&
                     cp(dyn_hist, D.dh, sizeof(double) * B * S * nd * 4) && cp(steps, D.k, sizeof(int32_t) * B) &&
                     cp(flags, D.flags, sizeof(int32_t) * B);
     return ok ? OBCA_OK : OBCA_E_HIP;

@@ -50,7 +50,7 @@ struct Dev {
     int32_t *status[MAX_GROUPS], *iters[MAX_GROUPS], *status8[MAX_GROUPS], *iters8[MAX_GROUPS];
     // history (what the reference hands to its plot routine, :435-441)
     double *xc, *uc, *Tc, *xol, *dh;
-    int32_t *vh, *ih;
+    int32_t *vh, *ih, *sh;
 };
 
 // one polygon edge -> one row [a0 a1 | b]; branch order and exact comparisons of src/model_obstacle.py:63-89
@@ -230,6 +230,7 @@ RO_FN void finish(const Dev& D, int b) {
     if (g > 0 && D.var8[g][b] == 8) { st = D.status8[g][b]; it += D.iters8[g][b]; variant = 8; }
     D.vh[(size_t)b * D.S + k] = variant;
     D.ih[(size_t)b * D.S + k] = it;
+    D.sh[(size_t)b * D.S + k] = st;
     if (!status_feasible(st)) { D.flags[b] = OBCA_DONE_FAILED; return; }
     const double* xo = D.xopt[g] + (size_t)b * 3 * N1;
     const double* uo = D.uopt[g] + (size_t)b * 2 * N;
