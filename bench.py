@@ -90,7 +90,8 @@ def closed_loop_c5(B, n_dyn=2):
     o = {k: v.cpu().numpy() for k, v in dr.read().items()}
     ok, tried = int(o["steps"].sum()), int((o["variant"] > 0).sum())
     return {"workload": "C5 (SURVEY 8d): %d closed-loop rollouts, N=5, walls + random box + %d moving 3x3 boxes (lidar gate 10 m), "
-                        "<=30 steps each, obca_mpc4 / obca_mpc6 -> obca_mpc8 as the reference dispatches them" % (B, n_dyn),
+                        "<=30 steps each, obca_mpc4 / obca_mpc6 -> obca_mpc8 as the reference dispatches them; harness and "
+                        "solves in one persistent kernel (obca_rollouts_run)" % (B, n_dyn),
             "value": ok / dt, "unit": "converged closed-loop MPC steps/s", "seconds": dt, "converged_steps": ok,
             "attempted_steps": tried, "rollouts_to_step_cap": int((o["flags"] == 2).sum()),
             "rollouts_stopped_infeasible": int((o["flags"] == 3).sum()),
@@ -204,6 +205,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
         if world == 1 and args.closed_loop_rollouts > 0:
             line["closed_loop"] = closed_loop_c5(args.closed_loop_rollouts)
+            # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes
+            line["closed_loop_static"] = closed_loop_c5(B, n_dyn=0)
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

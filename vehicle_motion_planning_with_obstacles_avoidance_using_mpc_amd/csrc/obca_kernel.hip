@@ -1580,9 +1580,8 @@ extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A
 // is the descriptor obca_solve_batch would use for problem shape g (= sensed moving obstacles), a = 1 the retry.
 #include "obca_rollout_core.h"
 
-extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
-    const rollout::Dev& D = *Dp;
+template <int RPL>
+__device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* __restrict__ launches, int n_steps) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= D.B) return;
     for (int step = 0; step < n_steps; ++step) {
@@ -1597,10 +1596,20 @@ obca_rollout_fused_kernel(const rollout::Dev* __restrict__ Dp, const ObcaLaunch*
                 __syncthreads();
                 if (D.var8[g][b] != 8) break;
             }
-            obca_ipm_body<6>(launches[g + attempt * rollout::MAX_GROUPS], b);
+            obca_ipm_body<RPL>(launches[g + attempt * rollout::MAX_GROUPS], b);
             __syncthreads();
         }
         if (lane == 0) rollout::finish(D, b);
         __syncthreads();
     }
+}
+
+// _r4: every shape of the rollout has <= 256 rows (static obstacles only at N=5); _r6: <= 384 rows
+extern "C" __global__ void __launch_bounds__(64)
+obca_rollout_fused_kernel_r4(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
+    rollout_fused_body<4>(*Dp, launches, n_steps);
+}
+extern "C" __global__ void __launch_bounds__(64)
+obca_rollout_fused_kernel_r6(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
+    rollout_fused_body<6>(*Dp, launches, n_steps);
 }

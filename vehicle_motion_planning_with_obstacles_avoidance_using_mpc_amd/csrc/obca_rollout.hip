@@ -8,7 +8,8 @@
 #include "obca_device.h"
 #include "obca_rollout_core.h"
 
-extern "C" __global__ void obca_rollout_fused_kernel(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
+extern "C" __global__ void obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
+extern "C" __global__ void obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
 
 namespace {
 
@@ -46,6 +47,7 @@ struct obca_rollouts {
     ObcaLaunch* dL;
     ObcaLaunch hL[2 * rollout::MAX_GROUPS];
     bool fused_ok;
+    int32_t rows_max;
     int64_t lds_max;
     int mode;                 /* 0 auto (fused when every shape fits the wave kernel), 1 lock-step launches */
     // constants owned by the handle (copied at reset so the caller's buffers may go away)
@@ -169,6 +171,7 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
     // descriptors of the fused kernel: the launch obca_solve_batch would make per shape, first attempt and retry
     r->fused_ok = true;
     r->lds_max = 0;
+    r->rows_max = 0;
     memset(r->hL, 0, sizeof(r->hL));
     for (int g = 0; g <= D.n_dyn; ++g)
         for (int a = 0; a < 2; ++a) {
@@ -181,12 +184,14 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
             if (rc != OBCA_OK) return rc;
             if (!wave_ok) r->fused_ok = false;
             if (lds > r->lds_max) r->lds_max = lds;
+            if (r->hL[g + a * rollout::MAX_GROUPS].R_max > r->rows_max) r->rows_max = r->hL[g + a * rollout::MAX_GROUPS].R_max;
         }
     if (hipMemcpyAsync(r->dD, &r->D, sizeof(rollout::Dev), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(r->dL, r->hL, sizeof(r->hL), hipMemcpyHostToDevice, s) != hipSuccess)
         return OBCA_E_HIP;
     if (r->fused_ok && r->lds_max > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(obca_rollout_fused_kernel),
+        hipFuncSetAttribute(r->rows_max <= 256 ? reinterpret_cast<const void*>(obca_rollout_fused_kernel_r4)
+                                               : reinterpret_cast<const void*>(obca_rollout_fused_kernel_r6),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_max) != hipSuccess)
         return OBCA_E_HIP;
     r->ready = true;
@@ -229,8 +234,12 @@ extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_st
     if (!r || !r->ready || n_steps < 0) return OBCA_E_INVAL;
     if (n_steps == 0) return OBCA_OK;
     if (r->fused_ok && r->mode == 0) {
-        hipLaunchKernelGGL(obca_rollout_fused_kernel, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
-                           (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
+        if (r->rows_max <= 256)
+            hipLaunchKernelGGL(obca_rollout_fused_kernel_r4, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
+        else
+            hipLaunchKernelGGL(obca_rollout_fused_kernel_r6, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
         return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
     }
     for (int i = 0; i < n_steps; ++i) {
