@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0,'.')
+sys.path.insert(0, '.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
 B=int(sys.argv[1]) if len(sys.argv)>1 else 1024

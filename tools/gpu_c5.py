@@ -1,7 +1,7 @@
 """dev tool: closed-loop (C5) throughput on the device-resident rollouts"""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, '.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -1,5 +1,5 @@
 import sys, ctypes, numpy as np, torch
-sys.path.insert(0,'.')
+sys.path.insert(0, '.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import _lib, scenarios as sc
 _lib.LIB_PATH = _lib.LIB_PATH.replace('libobca_mpc.so', 'libobca_mpc_prof.so')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
