@@ -184,6 +184,10 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
             if (rc != OBCA_OK) return rc;
             if (!wave_ok) r->fused_ok = false;
             if (lds > r->lds_max) r->lds_max = lds;
+            // groups g >= 1 only ever solve the fixed-time variants, whose layouts have 3 (obca_mpc6) / 5 (obca_mpc8) rows
+            // less than the free-time layout the handle sizes for: with one sensed box at N=5 that is 256 instead of 259
+            // rows, which fits the 4-rows-per-lane kernel
+            if (g > 0) r->hL[g + a * rollout::MAX_GROUPS].R_max -= 3;
             if (r->hL[g + a * rollout::MAX_GROUPS].R_max > r->rows_max) r->rows_max = r->hL[g + a * rollout::MAX_GROUPS].R_max;
         }
     if (hipMemcpyAsync(r->dD, &r->D, sizeof(rollout::Dev), hipMemcpyHostToDevice, s) != hipSuccess ||
