@@ -72,13 +72,13 @@ def cpu_baseline(batch, N, seconds=20.0):
             "sample": "%d instances of the same batch, numpy dense restatement (oracle/ipm_dense.py), %.1f s" % (n, dt)}
 
 
-def closed_loop_c5(B, n_dyn=2):
+def closed_loop_c5(B, n_dyn=2, warm_start=None):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds resident in HBM before the clock starts."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
     w = pack_worlds([sc.make_world_c5(i, n_dyn=n_dyn) for i in range(B)])
-    dr = DeviceRollouts(w, N=5)
+    dr = DeviceRollouts(w, N=5, warm_start=warm_start)
     dr.run(1)
     torch.cuda.synchronize()
     dr.reset()
@@ -207,6 +207,8 @@ def main():
             line["closed_loop"] = closed_loop_c5(args.closed_loop_rollouts)
             # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes
             line["closed_loop_static"] = closed_loop_c5(B, n_dyn=0)
+            # optional extension, NOT reference behaviour (the reference cold-starts every solve): shifted previous plan
+            line["closed_loop_static_warm_start"] = closed_loop_c5(B, n_dyn=0, warm_start=0.1)
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

@@ -107,6 +107,16 @@ int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
                      double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
                      double* info, void* hip_stream);
 
+/* Optional warm start -- NOT reference behaviour (every solve of the reference is a cold start from zeros, T = 1,
+ * src/obca.py:856), off by default, for receding-horizon callers that re-solve a problem one step later.
+ * z: device buffer [max_batch, obca_primal_size(dims)] owned by the caller.  While set, every solve that ends
+ * converged/acceptable stores its primal vector (poses, inputs, lambda, mu, time scale) there, and every solve of an
+ * instance b with use[b] != 0 (use == NULL: all) starts from the stored vector moved one horizon stage forward (last
+ * stage repeated) with barrier parameter mu_init instead of 0.1.  Which local optimum is found may differ from the cold
+ * start's.  z == NULL switches it off. */
+int64_t obca_primal_size(const obca_dims* dims);
+int obca_set_warm_start(obca_handle* h, double* z, const int32_t* use, double mu_init);
+
 /* Kernel selection: 0 = auto (default; also env OBCA_MODE): the wave-per-instance kernel whenever the shape fits one CU's
  * LDS, else the lane-per-instance kernel; 1 = wave-per-instance (one wavefront per instance, working set in LDS);
  * 2 = lane-per-instance (64 instances per wavefront, working set in an HBM workspace owned by the handle; any shape,
@@ -175,6 +185,11 @@ int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
  * back; results are identical to n_steps calls of obca_rollouts_step.  Mode 1 forces the lock-step launches. */
 int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_stream);
 int obca_rollouts_set_mode(obca_rollouts* r, int mode);
+
+/* Optional, NOT reference behaviour (see obca_set_warm_start): a step whose problem shape equals the previous step's
+ * starts from the previous plan moved one stage forward with barrier parameter mu_init.  Call before
+ * obca_rollouts_reset; enable = 0 restores the reference's cold starts. */
+int obca_rollouts_set_warm_start(obca_rollouts* r, int enable, double mu_init);
 
 /* Copy state and history to caller-owned DEVICE buffers (any may be NULL): x_closed [B,max_steps+1,3],
  * u_closed [B,max_steps,2], T_closed [B,max_steps], x_openloop [B,max_steps,3,N+1], variant_hist [B,max_steps]

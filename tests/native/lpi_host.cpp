@@ -15,12 +15,14 @@ static void sym(double* d, const double* s, int k) {
     for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) d[k * a + b] = 0.5 * (s[k * a + b] + s[k * b + a]);
 }
 
-extern "C" int lpi_host_solve_batch(int N, int n_obs, const int* m, const int* variant, int B,
-                                    const double* x0, const double* u0, const double* xref, const double* A,
-                                    const double* b, const double* Ts, const double* term, const HostParams* p,
-                                    double* xopt, double* uopt, double* ts_opt, int* status, int* iters, double* info) {
+extern "C" int lpi_host_solve_batch_warm(int N, int n_obs, const int* m, const int* variant, int B,
+                                         const double* x0, const double* u0, const double* xref, const double* A,
+                                         const double* b, const double* Ts, const double* term, const HostParams* p,
+                                         double* xopt, double* uopt, double* ts_opt, int* status, int* iters, double* info,
+                                         double* warm_z, const int* warm_use, double warm_mu) {
     ObcaLaunch L;
     memset(&L, 0, sizeof(L));
+    L.warm_z = warm_z; L.warm_use = warm_use; L.warm_mu = warm_mu;
     int offm[OBCA_MAX_OBST + 1];
     int M = 0;
     offm[0] = 0;
@@ -49,4 +51,12 @@ extern "C" int lpi_host_solve_batch(int N, int n_obs, const int* m, const int* v
     for (int i = 0; i < B; ++i) lpi::run_instance(L, ws, stride, (size_t)i, offm);
     free(ws);
     return 0;
+}
+
+extern "C" int lpi_host_solve_batch(int N, int n_obs, const int* m, const int* variant, int B,
+                                    const double* x0, const double* u0, const double* xref, const double* A,
+                                    const double* b, const double* Ts, const double* term, const HostParams* p,
+                                    double* xopt, double* uopt, double* ts_opt, int* status, int* iters, double* info) {
+    return lpi_host_solve_batch_warm(N, n_obs, m, variant, B, x0, u0, xref, A, b, Ts, term, p, xopt, uopt, ts_opt, status, iters,
+                                     info, nullptr, nullptr, 0.0);
 }

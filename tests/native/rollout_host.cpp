@@ -10,7 +10,8 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
                                 double sense_dis, const HostParams* hp, int n_steps,
                                 double* x_closed, double* u_closed, double* T_closed, double* x_openloop,
                                 int* variant_hist, int* iters_hist, int* status_hist, double* dyn_hist, int* steps, int* flags,
-                                double* xref_hist /* [B,S,3,N+1] solver reference of every step, may be NULL */) {
+                                double* xref_hist /* [B,S,3,N+1] solver reference of every step, may be NULL */,
+                                double warm_mu /* > 0: warm start as obca_rollouts_set_warm_start does */) {
     using namespace rollout;
     Dev D;
     memset(&D, 0, sizeof(D));
@@ -32,7 +33,9 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
         D.var[g] = ia(B); D.var8[g] = ia(B); D.A[g] = da(B * N1 * Mg * 2); D.b[g] = da(B * N1 * Mg);
         D.xopt[g] = da(B * 3 * N1); D.uopt[g] = da(B * 2 * N); D.ts[g] = da(B);
         D.status[g] = ia(B); D.iters[g] = ia(B); D.status8[g] = ia(B); D.iters8[g] = ia(B);
+        if (warm_mu > 0.0) { D.wz[g] = da(B * (N1 * (3 + Mg + 4 * (d->n_static + g)) + 2 * N + 1)); D.wuse[g] = ia(B); }
     }
+    D.warm = warm_mu > 0.0 ? 1 : 0;
     for (int b = 0; b < D.B; ++b) reset(D, b, start, dyn, Ts0);
     for (int step = 0; step < n_steps; ++step) {
         for (int b = 0; b < D.B; ++b) {
@@ -45,13 +48,15 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
             int m[OBCA_MAX_OBST];
             for (int i = 0; i < d->n_static; ++i) m[i] = d->m_static[i];
             for (int i = 0; i < g; ++i) m[d->n_static + i] = 4;
-            int rc = lpi_host_solve_batch(D.N, d->n_static + g, m, D.var[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term,
-                                          hp, D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr);
+            int rc = lpi_host_solve_batch_warm(D.N, d->n_static + g, m, D.var[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term,
+                                               hp, D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr,
+                                               D.warm ? D.wz[g] : nullptr, D.warm ? D.wuse[g] : nullptr, warm_mu);
             if (rc) return rc;
             if (g == 0) continue;
             for (int b = 0; b < D.B; ++b) make_retry(D, g, b);
-            rc = lpi_host_solve_batch(D.N, d->n_static + g, m, D.var8[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term,
-                                      hp, D.xopt[g], D.uopt[g], D.ts[g], D.status8[g], D.iters8[g], nullptr);
+            rc = lpi_host_solve_batch_warm(D.N, d->n_static + g, m, D.var8[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term,
+                                           hp, D.xopt[g], D.uopt[g], D.ts[g], D.status8[g], D.iters8[g], nullptr,
+                                           D.warm ? D.wz[g] : nullptr, D.warm ? D.wuse[g] : nullptr, warm_mu);
             if (rc) return rc;
         }
         for (int b = 0; b < D.B; ++b) finish(D, b);

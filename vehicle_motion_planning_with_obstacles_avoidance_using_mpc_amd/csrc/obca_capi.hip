@@ -21,6 +21,9 @@ struct obca_handle {
     double* prof;
     int mode;                 /* 0 auto, 1 wave-per-instance (LDS), 2 lane-per-instance (HBM workspace) */
     bool wave_ok;             /* the LDS kernel can hold this shape */
+    double* warm_z;           /* obca_set_warm_start */
+    const int32_t* warm_use;
+    double warm_mu;
     double* ws;               /* lane kernel workspace, allocated on first use */
     size_t ws_stride;
     int* d_offm;
@@ -102,6 +105,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     h->ws_stride = ((size_t)d->max_batch + 63) / 64 * 64;
     h->ws_doubles = lpi::carve(d->N, d->n_obs, h->M, h->n_max, h->R_max).total;
     h->prof = nullptr;
+    h->warm_z = nullptr; h->warm_use = nullptr; h->warm_mu = 0.0;
     *out = h;
     return OBCA_OK;
 }
@@ -117,6 +121,19 @@ extern "C" int obca_set_mode(obca_handle* h, int mode) {
     if (!h || mode < 0 || mode > 2) return OBCA_E_INVAL;
     if (mode == 1 && !h->wave_ok) return OBCA_E_LDS;
     h->mode = mode;
+    return OBCA_OK;
+}
+
+extern "C" int64_t obca_primal_size(const obca_dims* d) {
+    if (!dims_ok(d)) return -1;
+    int M = 0;
+    for (int i = 0; i < d->n_obs; ++i) M += d->m[i];
+    return (int64_t)(d->N + 1) * (3 + M + 4 * d->n_obs) + 2 * d->N + 1;
+}
+
+extern "C" int obca_set_warm_start(obca_handle* h, double* z, const int32_t* use, double mu_init) {
+    if (!h || (z && !(mu_init > 0.0))) return OBCA_E_INVAL;
+    h->warm_z = z; h->warm_use = z ? use : nullptr; h->warm_mu = mu_init;
     return OBCA_OK;
 }
 
@@ -138,6 +155,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     for (int i = 0; i <= OBCA_MAX_OBST; ++i) L.offm[i] = h->offm[i];
     L.variant = variant; L.x0 = x0; L.u0 = u0; L.xref = xref; L.A = A; L.b = b; L.Ts = Ts; L.term = term;
     L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info; L.prof = h->prof;
+    L.warm_z = h->warm_z; L.warm_use = h->warm_use; L.warm_mu = h->warm_mu;
     auto cpw = [](ObcaWeightsDev& d, const obca_weights& s) {
         // the reference's double loops use Q[i,j] for every (i,j): only the symmetric part matters
         for (int a = 0; a < 3; ++a)

@@ -59,6 +59,9 @@ struct ObcaLaunch {
     int32_t *status, *iters;
     double* info;
     double* prof;          /* [B,20] per-phase cycle counters, only written by -DOBCA_PROFILE builds */
+    double* warm_z;        /* [B,n_max] primal vector of the last successful solve (in/out) or NULL: obca_set_warm_start */
+    const int32_t* warm_use; /* [B] != 0: start from warm_z shifted by one stage; NULL = every instance          */
+    double warm_mu;        /* barrier parameter a warm-started solve begins with                                 */
     ObcaParamsDev prm;
 };
 

@@ -1180,11 +1180,30 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
 
-    // ---- start point: zeros, Topt = 1 (obca.py:856) -------------------------------------------------------
-    for (int t = lane; t < L.n; t += 64) S.x[t] = 0.0;
+    // ---- start point: zeros, Topt = 1 (obca.py:856) -- or, when the caller asked for it (obca_set_warm_start; the
+    // reference never does), the previous solve's primal vector moved one stage forward (last stage repeated)
+    const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
+    if (warm) {
+        const double* zp = A.warm_z + (size_t)inst * A.n_max;
+        const int blk = L.NS - 2;                              // pose, lambda, mu of a stage (inputs handled apart)
+        for (int t = lane; t < (L.N + 1) * blk; t += 64) {
+            const int k = t / blk, q = t - k * blk;
+            const int ks = k < L.N ? k + 1 : L.N;
+            const int dst = (q < 3 ? L.ip(k) + q : L.il(k) + (q - 3));
+            const int src = (q < 3 ? L.ip(ks) + q : L.il(ks) + (q - 3));
+            S.x[dst] = zp[src];
+        }
+        for (int t = lane; t < 2 * L.N; t += 64) {
+            const int k = t >> 1, j = t & 1;
+            S.x[L.iu(k) + j] = zp[L.iu(k + 1 < L.N ? k + 1 : L.N - 1) + j];
+        }
+        if (L.free_T && lane == 0) S.x[L.iT()] = zp[L.iT()];
+    } else {
+        for (int t = lane; t < L.n; t += 64) S.x[t] = 0.0;
+    }
     for (int t = lane; t < 2 * L.npair; t += 64) S.nu[t] = 0.0;
     SYNC();
-    if (L.free_T && lane == 0) S.x[L.iT()] = 1.0;
+    if (!warm && L.free_T && lane == 0) S.x[L.iT()] = 1.0;
     SYNC();
     int status = OBCA_STATUS_MAXITER;
     int it = 0, nfact = 0;
@@ -1203,7 +1222,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     }
     SYNC();
     f = eval_objective<true>(L, S, in, S.x, sf, lane);
-    double mu = OBCA_MU_INIT;
+    double mu = warm ? A.warm_mu : OBCA_MU_INIT;
     // rows: bounds, slacks with bound push, elastic variables on their 1-d central path
     Rows<RPL> W;
     {
@@ -1549,6 +1568,10 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     if ((status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE) && elastic_max > O.feas_tol)
         status = OBCA_STATUS_INFEASIBLE;
 
+    if (A.warm_z != nullptr && (status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE)) {
+        double* zp = A.warm_z + (size_t)inst * A.n_max;        // kept for the next solve of this instance
+        for (int t = lane; t < L.n; t += 64) zp[t] = S.x[t];
+    }
     // ---- outputs (last iterate on failure, like the reference's except-branch) --------------------------------
     {
         const int N1 = L.N + 1;

@@ -989,13 +989,31 @@ LPI_FN double row_barrier_lpi(double lo, double up, bool eq, double s, double p,
 // ---------------------------------------------------------------- one instance, start to finish
 struct Out { int status, iters, nfact; double f, elastic, E0, ts_opt; };
 
-LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaOptsDev& O) {
+// zwarm != nullptr: start from that primal vector moved one stage forward (last stage repeated) with barrier
+// parameter mu_warm (obca_set_warm_start); otherwise the reference's cold start
+LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaOptsDev& O,
+                          const double* zwarm = nullptr, double mu_warm = OBCA_MU_INIT) {
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
-    for (int t = 0; t < L.n; ++t) S.x[t] = 0.0;
+    if (zwarm) {
+        const int blk = L.NS - 2;
+        for (int k = 0; k <= L.N; ++k) {
+            const int ks = k < L.N ? k + 1 : L.N;
+            for (int q = 0; q < blk; ++q) {
+                const int dst = (q < 3 ? L.ip(k) + q : L.il(k) + (q - 3));
+                const int src = (q < 3 ? L.ip(ks) + q : L.il(ks) + (q - 3));
+                S.x[dst] = zwarm[src];
+            }
+        }
+        for (int k = 0; k < L.N; ++k)
+            for (int j = 0; j < 2; ++j) S.x[L.iu(k) + j] = zwarm[L.iu(k + 1 < L.N ? k + 1 : L.N - 1) + j];
+        if (L.free_T) S.x[L.iT()] = zwarm[L.iT()];
+    } else {
+        for (int t = 0; t < L.n; ++t) S.x[t] = 0.0;
+        if (L.free_T) S.x[L.iT()] = 1.0;
+    }
     for (int t = 0; t < 2 * L.npair; ++t) S.nu[t] = 0.0;
-    if (L.free_T) S.x[L.iT()] = 1.0;
     Out o;
     o.status = OBCA_STATUS_MAXITER; o.iters = 0; o.nfact = 0; o.E0 = INFINITY; o.elastic = 0.0;
     double sf = 1.0, rho = O.rho;
@@ -1009,7 +1027,7 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
         rho = O.rho * sf;
     }
     f = eval_objective<true>(L, S, in, S.x, sf, 0);
-    double mu = OBCA_MU_INIT;
+    double mu = zwarm ? mu_warm : OBCA_MU_INIT;
     bool bad_bounds = false;
     for (int r = 0; r < L.R; ++r) {
         double lo, up;
@@ -1321,7 +1339,12 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     }
     const double dis = (S.xref[0 * N1 + L.N] - in.x0[0]) + (S.xref[1 * N1 + L.N] - in.x0[1]);
     in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
-    const Out o = solve_instance(L, S, in, A.prm.opt);
+    const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
+    const Out o = solve_instance(L, S, in, A.prm.opt, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
+    if (A.warm_z != nullptr && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE)) {
+        double* zp = A.warm_z + inst * (size_t)A.n_max;
+        for (int t = 0; t < L.n; ++t) zp[t] = S.x[t];
+    }
     double* xo = A.xopt + inst * 3 * N1;
     double* uo = A.uopt + inst * 2 * L.N;
     for (int j = 0; j < 3; ++j) for (int k = 0; k < N1; ++k) xo[j * N1 + k] = S.x[L.ip(k) + j];

@@ -50,6 +50,7 @@ struct obca_rollouts {
     int32_t rows_max;
     int64_t lds_max;
     int mode;                 /* 0 auto (fused when every shape fits the wave kernel), 1 lock-step launches */
+    double warm_mu;           /* > 0: warm start enabled */
     // constants owned by the handle (copied at reset so the caller's buffers may go away)
     double *goal, *path, *As, *bs;
     int32_t* path_len;
@@ -132,7 +133,7 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
             rc = OBCA_E_HIP;
     }
     if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
-    r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0;
+    r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0; r->warm_mu = 0.0;
     if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS))) rc = OBCA_E_NOMEM;
     if (rc != OBCA_OK) { obca_rollouts_destroy(r); return rc; }
     *out = r;
@@ -168,6 +169,10 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
     D.ego_w = params->ego[1];
     hipLaunchKernelGGL(rollout_reset_kernel, dim3((D.B + 63) / 64), dim3(64), 0, s, D, start, dyn, Ts0);
     if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
+    for (int g = 0; g <= D.n_dyn; ++g) {
+        const int rc = obca_set_warm_start(r->solver[g], D.warm ? D.wz[g] : nullptr, D.warm ? D.wuse[g] : nullptr, r->warm_mu);
+        if (rc != OBCA_OK) return rc;
+    }
     // descriptors of the fused kernel: the launch obca_solve_batch would make per shape, first attempt and retry
     r->fused_ok = true;
     r->lds_max = 0;
@@ -225,6 +230,27 @@ extern "C" int obca_rollouts_step(obca_rollouts* r, void* hip_stream) {
     }
     hipLaunchKernelGGL(rollout_finish_kernel, grid, block, 0, s, D);
     if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
+    return OBCA_OK;
+}
+
+extern "C" int obca_rollouts_set_warm_start(obca_rollouts* r, int enable, double mu_init) {
+    if (!r || (enable && !(mu_init > 0.0))) return OBCA_E_INVAL;
+    rollout::Dev& D = r->D;
+    if (enable && !D.wz[0]) {
+        for (int g = 0; g <= D.n_dyn; ++g) {
+            obca_dims sd;
+            memset(&sd, 0, sizeof(sd));
+            sd.N = D.N; sd.n_obs = D.n_static + g; sd.max_batch = D.B; sd.device = r->dims.device;
+            for (int i = 0; i < D.n_static; ++i) sd.m[i] = r->dims.m_static[i];
+            for (int i = 0; i < g; ++i) sd.m[D.n_static + i] = 4;
+            const int64_t n = obca_primal_size(&sd);
+            if (n < 0) return OBCA_E_INVAL;
+            if (!dev_alloc(r, D.wz[g], (size_t)D.B * (size_t)n) || !dev_alloc(r, D.wuse[g], (size_t)D.B)) return OBCA_E_NOMEM;
+        }
+    }
+    D.warm = enable ? 1 : 0;
+    r->warm_mu = enable ? mu_init : 0.0;
+    r->ready = false;                      // takes effect with the next obca_rollouts_reset
     return OBCA_OK;
 }
 

@@ -51,6 +51,11 @@ struct Dev {
     // history (what the reference hands to its plot routine, :435-441)
     double *xc, *uc, *Tc, *xol, *dh;
     int32_t *vh, *ih, *sh;
+    // optional warm start (obca_rollouts_set_warm_start): per group the primal vectors kept by the solver and the flags
+    // telling it which rollouts may start from them
+    int32_t warm;
+    double* wz[MAX_GROUPS];
+    int32_t* wuse[MAX_GROUPS];
 };
 
 // one polygon edge -> one row [a0 a1 | b]; branch order and exact comparisons of src/model_obstacle.py:63-89
@@ -104,9 +109,10 @@ RO_FN void reset(const Dev& D, int b, const double* start, const double* dyn0, d
 RO_FN void prepare(const Dev& D, int b) {
     RO_EXACT
     const int N = D.N, N1 = N + 1, nd = D.n_dyn;
-    for (int g = 0; g <= nd; ++g) D.var[g][b] = 0;
+    for (int g = 0; g <= nd; ++g) { D.var[g][b] = 0; if (D.warm) D.wuse[g][b] = 0; }
     if (D.flags[b] != OBCA_RUN) return;
     const int k = D.k[b];
+    const int prev_group = D.sel[b];                 // problem shape of the previous step (which succeeded if k > 0)
     double Ts_opt = D.Ts_opt[b];
     const double* x0 = D.x0 + 3 * b;
 
@@ -175,6 +181,7 @@ RO_FN void prepare(const Dev& D, int b) {
         }
         D.sel[b] = 0;
         D.var[0][b] = 4;
+        if (D.warm && k > 0 && prev_group == 0) D.wuse[0][b] = 1;
         return;
     }
 
@@ -211,6 +218,7 @@ RO_FN void prepare(const Dev& D, int b) {
     }
     D.sel[b] = g;
     D.var[g][b] = 6;
+    if (D.warm && k > 0 && prev_group == g) D.wuse[g][b] = 1;
 }
 
 RO_FN bool status_feasible(int st) { return st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE; }

@@ -155,7 +155,9 @@ class DeviceRollouts:
     """B rollouts on one GPU.  ``step()`` enqueues one receding-horizon step of every running rollout;
     ``run()`` all of them; ``read()`` returns state and history (torch tensors on the device)."""
 
-    def __init__(self, worlds, N=5, params=None, Ts0=0.1, max_steps=30, device=None):
+    def __init__(self, worlds, N=5, params=None, Ts0=0.1, max_steps=30, device=None, warm_start=None):
+        """warm_start: None = the reference's cold start of every solve; a float mu_init = start each step whose
+        problem shape equals the previous step's from the shifted previous plan (NOT reference behaviour)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceRollouts needs a ROCm GPU; there is no CPU fallback on the product path")
@@ -171,6 +173,8 @@ class DeviceRollouts:
         self._h = h
         self.steps_enqueued = 0
         self.mode = 0
+        if warm_start is not None:
+            _lib.check(self.lib.obca_rollouts_set_warm_start(self._h, 1, float(warm_start)))
         self.reset()
 
     def _stream(self):
