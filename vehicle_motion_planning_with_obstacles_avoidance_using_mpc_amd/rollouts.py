@@ -213,7 +213,7 @@ class DeviceRollouts:
         f = lambda *shape: t.empty(*shape, dtype=t.float64, device=self.device)
         i = lambda *shape: t.empty(*shape, dtype=t.int32, device=self.device)
         out = {"x_closed": f(B, S + 1, 3), "u_closed": f(B, S, 2), "T_closed": f(B, S), "x_openloop": f(B, S, 3, N1),
-               "variant": i(B, S), "iters": i(B, S), "status": i(B, S), "dyn": f(B, S, max(nd, 1), 4), "steps": i(B), "flags": i(B)}
+               "variant": i(B, S), "iters": i(B, S), "status": i(B, S), "dyn": f(B, S, nd, 4) if nd else t.zeros(B, S, 1, 4, dtype=t.float64, device=self.device), "steps": i(B), "flags": i(B)}
         order = ("x_closed", "u_closed", "T_closed", "x_openloop", "variant", "iters", "status", "dyn", "steps", "flags")
         ptrs = [ctypes.c_void_p(out[k].data_ptr()) if (k != "dyn" or nd) else None for k in order]
         _lib.check(self.lib.obca_rollouts_read(self._h, *ptrs, self._stream()))
