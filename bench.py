@@ -72,6 +72,29 @@ def cpu_baseline(batch, N, seconds=20.0):
             "sample": "%d instances of the same batch, numpy dense restatement (oracle/ipm_dense.py), %.1f s" % (n, dt)}
 
 
+def cpu_structured(batch, N, seconds=10.0):
+    """Context, not the oracle: the GPU kernels' own structured algorithm (csrc/obca_lpi_core.h, the portable core of
+    the lane kernel) compiled for the host and run with OpenMP over instances on all cores (tests/native)."""
+    try:
+        from tests import native_build
+        native_build.load()
+    except Exception as e:          # no g++ / build failed: the figure is optional
+        return {"value": None, "note": "host build of the structured core unavailable: %r" % (e,)}
+    cores = os.cpu_count() or 1
+    n, t0 = 0, time.time()
+    chunk = 4 * cores
+    solved = 0
+    while time.time() - t0 < seconds and n + chunk <= batch["x0"].shape[0]:
+        sl = slice(n, n + chunk)
+        st = native_build.lpi_solve(4, N, batch["m"], batch["x0"][sl], batch["u0"][sl], batch["xref"][sl], batch["A"][sl],
+                                    batch["b"][sl], batch["Ts"][sl])["status"]
+        solved += int(np.sum((st == 0) | (st == 1)))
+        n += chunk
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "MPC steps/s", "cores": cores, "solved": solved,
+            "sample": "%d instances of the same batch, structured core on the host, %d OpenMP threads, %.1f s" % (n, cores, dt)}
+
+
 def closed_loop_c5(B, n_dyn=2, warm_start=None):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds resident in HBM before the clock starts."""
@@ -203,6 +226,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
+            line["cpu_structured_core"] = cpu_structured(batch, N)
         if world == 1 and args.closed_loop_rollouts > 0:
             line["closed_loop"] = closed_loop_c5(args.closed_loop_rollouts)
             # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes

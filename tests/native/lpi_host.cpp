@@ -45,11 +45,31 @@ extern "C" int lpi_host_solve_batch_warm(int N, int n_obs, const int* m, const i
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
     const lpi::Carve c = lpi::carve(N, n_obs, M, L.n_max, L.R_max);
-    const size_t stride = (size_t)B;
-    double* ws = (double*)calloc((size_t)c.total * stride, sizeof(double));
-    if (!ws) return -12;
-    for (int i = 0; i < B; ++i) lpi::run_instance(L, ws, stride, (size_t)i, offm);
-    free(ws);
+    // The device lays the workspace out [element][instance] (stride = batch) so that a wave's accesses coalesce.  On the
+    // host the same indexing is exercised with stride = B when B <= 8; larger batches give every OpenMP thread one
+    // contiguous column (stride 1), which is what a CPU cache wants.
+    if (B <= 8) {
+        const size_t stride = (size_t)B;
+        double* ws = (double*)calloc((size_t)c.total * stride, sizeof(double));
+        if (!ws) return -12;
+        for (int i = 0; i < B; ++i) lpi::run_instance(L, ws, stride, (size_t)i, offm, (size_t)i);
+        free(ws);
+        return 0;
+    }
+    int fail = 0;
+#pragma omp parallel
+    {
+        double* ws = (double*)calloc((size_t)c.total, sizeof(double));
+        if (!ws) {
+#pragma omp atomic write
+            fail = 1;
+        }
+#pragma omp for schedule(dynamic, 1)
+        for (int i = 0; i < B; ++i)
+            if (ws) lpi::run_instance(L, ws, 1, (size_t)i, offm, 0);
+        free(ws);
+    }
+    if (fail) return -12;
     return 0;
 }
 

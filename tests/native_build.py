@@ -23,7 +23,7 @@ def load():
         return _lib
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in DEPS):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-Wno-unknown-pragmas",
                         SRC, "-o", OUT], check=True)
     _lib = ctypes.CDLL(OUT)
     _lib.lpi_host_solve_batch.restype = ctypes.c_int

@@ -11,5 +11,5 @@ obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* 
     if ((int)threadIdx.x >= ipw) return;
     const size_t inst = (size_t)blockIdx.x * ipw + threadIdx.x;
     if (inst >= (size_t)A.B) return;
-    lpi::run_instance(A, ws, (size_t)stride, inst, offm);
+    lpi::run_instance(A, ws, (size_t)stride, inst, offm, inst);
 }

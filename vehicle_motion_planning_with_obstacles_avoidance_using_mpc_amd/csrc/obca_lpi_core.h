@@ -1310,13 +1310,15 @@ LPI_FN void bind(Sh& S, const Carve& c, double* ws, size_t stride, size_t inst, 
 }
 
 // whole per-instance job: load inputs (instance-major C-ABI layout), solve, store outputs
-LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t inst, const int* offm) {
+// ws_col: which workspace column the instance uses (the device gives every instance its own: ws_col = inst; a host
+// thread pool can reuse one contiguous column per thread with stride 1)
+LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t inst, const int* offm, size_t ws_col) {
     if (A.variant[inst] == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; return; }
     Lay L;
     make_layout(L, A.N, A.nO, A.M, A.variant[inst]);
     const Carve c = carve(A.N, A.nO, A.M, A.n_max, A.R_max);
     Sh S;
-    bind(S, c, ws, stride, inst, offm);
+    bind(S, c, ws, stride, ws_col, offm);
     Inst in;
     const bool fr = L.free_T != 0;
     for (int j = 0; j < 9; ++j) { in.Q[j] = fr ? A.prm.free_time.Q[j] : A.prm.fixed_time.Q[j]; in.P[j] = fr ? A.prm.free_time.P[j] : A.prm.fixed_time.P[j]; }
