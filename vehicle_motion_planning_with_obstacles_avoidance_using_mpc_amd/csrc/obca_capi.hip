@@ -208,9 +208,9 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
         else
             hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
     } else {
-        if (!h->ws) {
-            if (hipMalloc(&h->ws, sizeof(double) * (size_t)h->ws_doubles * h->ws_stride) != hipSuccess) { h->ws = nullptr; return OBCA_E_NOMEM; }
-            if (hipMalloc(&h->d_offm, sizeof(int) * (OBCA_MAX_OBST + 1)) != hipSuccess) return OBCA_E_NOMEM;
+        if (!h->ws || !h->d_offm) {
+            if (!h->ws && hipMalloc(&h->ws, sizeof(double) * (size_t)h->ws_doubles * h->ws_stride) != hipSuccess) { h->ws = nullptr; return OBCA_E_NOMEM; }
+            if (!h->d_offm && hipMalloc(&h->d_offm, sizeof(int) * (OBCA_MAX_OBST + 1)) != hipSuccess) { h->d_offm = nullptr; return OBCA_E_NOMEM; }
             if (hipMemcpy(h->d_offm, h->offm, sizeof(int) * (OBCA_MAX_OBST + 1), hipMemcpyHostToDevice) != hipSuccess) return OBCA_E_HIP;
         }
         int ipw = 64;                               // one wave per SIMD (256 CUs x 4) before the waves get fatter
