@@ -83,3 +83,25 @@ def test_warm_start_option_reaches_the_same_plans_in_fewer_iterations():
     np.testing.assert_allclose(warm["x_closed"][:, :13], cold["x_closed"][:, :13], rtol=0, atol=1e-5)
     np.testing.assert_array_equal(warm["iters"][:, 0], cold["iters"][:, 0])        # step 0 is always a cold start
     assert warm["iters"][:, 1:12].mean() < 0.5 * cold["iters"][:, 1:12].mean()
+
+
+def test_history_export_matches_the_mirror_lists():
+    """N4: the batched history converts to the lists the reference's closedLoop hands to its plot routine"""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import reference_lists
+    settings = [make_world_c5(i) for i in range(2)]
+    w = pack_worlds(copy.deepcopy(settings))
+    out = native_build.rollout_run(w, 5, c_oracle.default_params(), 5)
+    for i, st in enumerate(settings):
+        cl, _ = host_rollout(copy.deepcopy(st), 5, 5)
+        lists = reference_lists(out, w, i)
+        assert len(lists["x_openLoop"]) == len(cl.x_openLoop) == cl.k
+        for a, b in zip(lists["x_openLoop"], cl.x_openLoop):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(np.array(lists["x_closed"]), np.array(cl.x_closed), rtol=0, atol=1e-7)
+        np.testing.assert_allclose(lists["Ts_opt"], cl.T_closed, rtol=0, atol=1e-7)
+        assert len(lists["dyn_loc"]) == len(cl.dyn_loc)
+        for a, b in zip(lists["dyn_loc"], cl.dyn_loc):
+            assert len(a) == len(b)
+            for va, vb in zip(a, b):
+                np.testing.assert_allclose(np.array(va[:5]), np.array(vb[:5]), rtol=0, atol=1e-9)
+                assert va[5] == vb[5]

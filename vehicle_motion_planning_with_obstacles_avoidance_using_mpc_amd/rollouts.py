@@ -229,3 +229,29 @@ class DeviceRollouts:
             self.close()
         except Exception:
             pass
+
+
+def reference_lists(out, worlds, i):
+    """History of rollout ``i`` in the form the reference's ``closedLoop`` keeps for its plot routine
+    (src/closed_loop.py:416-441, src/draw.py:333-456): ``x_openLoop`` list of (N+1,3) arrays, ``x_closed`` list of
+    poses, ``u_closed`` list of inputs, ``Ts_opt`` list, ``dyn_loc`` list (per step) of the present moving
+    rectangles as 5 clockwise vertices + lidar flag.  ``out`` = ``DeviceRollouts.read()`` (tensors or arrays)."""
+    from .model_obstacle import rectangle_vertices
+    g = lambda k: np.asarray(out[k].cpu() if hasattr(out[k], "cpu") else out[k])
+    k = int(g("steps")[i])
+    tried = int((g("variant")[i] > 0).sum())              # a failed last step still updated the obstacles
+    res = {"x_openLoop": [g("x_openloop")[i, j].T.copy() for j in range(k)],
+           "x_closed": [g("x_closed")[i, j].copy() for j in range(k + 1)],
+           "u_closed": [g("u_closed")[i, j].copy() for j in range(k)],
+           "Ts_opt": [float(v) for v in g("T_closed")[i, :k]],
+           "dyn_loc": []}
+    dyn = g("dyn")[i]
+    for j in range(tried):
+        verts = []
+        for q in range(worlds.n_dyn):
+            cx, cy, present, hit = dyn[j, q]
+            if present:
+                d = worlds.dyn[i, q]
+                verts.append(rectangle_vertices(cx, cy, d[2], d[3], d[4]) + [int(hit)])
+        res["dyn_loc"].append(verts)
+    return res
