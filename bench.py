@@ -183,6 +183,28 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
+    # configs[1] of BASELINE.json names the same workload at batch 1024: one wave per SIMD slot, so a launch lasts as
+    # long as its slowest instance -- reported beside the headline (batch 8192, the north-star's size)
+    small = None
+    if world == 1 and B >= 1024:
+        dv_s = {k: v[:1024].contiguous() for k, v in dv.items()}
+        s_small = BatchSolver(N, batch["m"], max_batch=1024, device=dev)
+        o_small = None
+        for _ in range(2):
+            o_small = s_small.solve(dv_s["variant"], dv_s["x0"], dv_s["u0"], dv_s["xref"], dv_s["A"], dv_s["b"], dv_s["Ts"],
+                                    dv_s["term"], prm, out=o_small)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            o_small = s_small.solve(dv_s["variant"], dv_s["x0"], dv_s["u0"], dv_s["xref"], dv_s["A"], dv_s["b"], dv_s["Ts"],
+                                    dv_s["term"], prm, out=o_small)
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t1
+        ok_s = int(((o_small.status == 0) | (o_small.status == 1)).sum())
+        small = {"workload": "C2 at batch 1024 (BASELINE configs[1])", "value": ok_s * args.steps / dt_s,
+                 "unit": "MPC steps/s", "ms_per_step": dt_s / args.steps * 1e3, "success_rate": ok_s / 1024.0}
+        s_small.close()
+
     ok = ((out.status == 0) | (out.status == 1)).sum().to(torch.float64)
     stats = torch.stack([torch.tensor(elapsed, dtype=torch.float64, device=dev), ok,
                          out.iters.to(torch.float64).sum(), out.info[:, 3].sum()])
@@ -223,6 +245,8 @@ def main():
                          "note": "latency/fp64-VALU bound by design (SURVEY 8d): ~1.3 KB of HBM traffic per solve; "
                                  "fp64_model_frac = steps/s x KKT factorisations x (N+1)(s^3/3+2s^2), s=32, over 78.6 TF"},
         }
+        if small is not None:
+            line["batch_1024"] = small
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
             line["cpu_structured_core"] = cpu_structured(batch, N)
