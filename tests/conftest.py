@@ -24,3 +24,11 @@ def nlp_golden():
 def harness_golden():
     with open(os.path.join(GOLDEN, "harness.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_library_built():
+    """libobca_mpc.so is a build product (git-ignored): make sure it exists before any test loads it.  A no-op when
+    the in-tree library is newer than its sources; never a fallback -- without hipcc this raises."""
+    import __graft_entry__ as ge
+    ge.build()
