@@ -10,6 +10,7 @@
 #include "obca_lpi_core.h"
 
 extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A);
+extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A);
 extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A);
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
@@ -92,8 +93,9 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
     if (hipSetDevice(d->device) != hipSuccess) { delete h; return OBCA_E_HIP; }
     if (h->wave_ok && h->lds_bytes > 64 * 1024) {
-        const void* fn = h->R_max <= 256 ? reinterpret_cast<const void*>(obca_ipm_kernel_r4)
-                                         : reinterpret_cast<const void*>(obca_ipm_kernel_r6);
+        const void* fn = h->R_max <= 256   ? reinterpret_cast<const void*>(obca_ipm_kernel_r4)
+                         : h->R_max <= 320 ? reinterpret_cast<const void*>(obca_ipm_kernel_r5)
+                                           : reinterpret_cast<const void*>(obca_ipm_kernel_r6);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
             delete h;
             return OBCA_E_HIP;
@@ -205,6 +207,8 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     if (!lane) {
         if (h->R_max <= 256)
             hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+        else if (h->R_max <= 320)
+            hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
         else
             hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
     } else {

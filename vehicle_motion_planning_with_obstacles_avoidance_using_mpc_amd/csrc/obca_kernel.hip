@@ -1593,6 +1593,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
 
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A) { obca_ipm_body<4>(A, blockIdx.x); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A) { obca_ipm_body<5>(A, blockIdx.x); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A) { obca_ipm_body<6>(A, blockIdx.x); }
 
 // ================================================================== fused closed loop
@@ -1631,6 +1632,10 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
 extern "C" __global__ void __launch_bounds__(64)
 obca_rollout_fused_kernel_r4(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
     rollout_fused_body<4>(*Dp, launches, n_steps);
+}
+extern "C" __global__ void __launch_bounds__(64)
+obca_rollout_fused_kernel_r5(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
+    rollout_fused_body<5>(*Dp, launches, n_steps);
 }
 extern "C" __global__ void __launch_bounds__(64)
 obca_rollout_fused_kernel_r6(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {

@@ -9,6 +9,7 @@
 #include "obca_rollout_core.h"
 
 extern "C" __global__ void obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
+extern "C" __global__ void obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
 extern "C" __global__ void obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
 
 namespace {
@@ -199,8 +200,9 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
         hipMemcpyAsync(r->dL, r->hL, sizeof(r->hL), hipMemcpyHostToDevice, s) != hipSuccess)
         return OBCA_E_HIP;
     if (r->fused_ok && r->lds_max > 64 * 1024 &&
-        hipFuncSetAttribute(r->rows_max <= 256 ? reinterpret_cast<const void*>(obca_rollout_fused_kernel_r4)
-                                               : reinterpret_cast<const void*>(obca_rollout_fused_kernel_r6),
+        hipFuncSetAttribute(r->rows_max <= 256   ? reinterpret_cast<const void*>(obca_rollout_fused_kernel_r4)
+                            : r->rows_max <= 320 ? reinterpret_cast<const void*>(obca_rollout_fused_kernel_r5)
+                                                 : reinterpret_cast<const void*>(obca_rollout_fused_kernel_r6),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_max) != hipSuccess)
         return OBCA_E_HIP;
     r->ready = true;
@@ -266,6 +268,9 @@ extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_st
     if (r->fused_ok && r->mode == 0) {
         if (r->rows_max <= 256)
             hipLaunchKernelGGL(obca_rollout_fused_kernel_r4, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
+        else if (r->rows_max <= 320)
+            hipLaunchKernelGGL(obca_rollout_fused_kernel_r5, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
                                (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
         else
             hipLaunchKernelGGL(obca_rollout_fused_kernel_r6, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
