@@ -14,6 +14,10 @@
  * All array arguments are DEVICE pointers (HBM resident, e.g. torch `data_ptr()`), row-major, fp64
  * unless noted; the caller owns every buffer.  Calls are asynchronous on the given HIP stream.
  * No C++ exception crosses this boundary.
+ *
+ * Threading: handles are independent; calls on ONE handle must be issued from one thread at a time and, when the
+ * lane-per-instance kernel runs (it owns a workspace inside the handle), must be ordered on one stream.  Different
+ * handles may be used concurrently from different threads and streams.
  */
 #ifndef OBCA_MPC_H
 #define OBCA_MPC_H
