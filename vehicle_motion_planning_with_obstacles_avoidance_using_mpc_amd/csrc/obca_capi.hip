@@ -37,7 +37,7 @@ constexpr int MW = OBCA_MAX_EDGES + 6;
 
 bool dims_ok(const obca_dims* d) {
     if (!d) return false;
-    if (d->N < 1 || d->N > 63) return false;
+    if (d->N < 1 || d->N > 127) return false;     // the wave kernel only ever sees N < 64 (rows / LDS), the lane kernel any
     if (d->n_obs < 1 || d->n_obs > OBCA_MAX_OBST) return false;
     for (int i = 0; i < d->n_obs; ++i)
         if (d->m[i] < 1 || d->m[i] > OBCA_MAX_EDGES) return false;

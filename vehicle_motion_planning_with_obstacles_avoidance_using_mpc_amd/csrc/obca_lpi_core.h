@@ -36,7 +36,7 @@ namespace lpi {
 
 constexpr int MW = OBCA_MAX_EDGES + 6;
 constexpr int NW = OBCA_MAX_EDGES + 4;
-constexpr int FILT_MAX = 32;
+constexpr int FILT_MAX = 128;
 
 struct SP {                      // strided pointer into the workspace
     double* p;

@@ -86,7 +86,7 @@ extern "C" void obca_rollouts_destroy(obca_rollouts* r) {
 extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** out) {
     if (!out) return OBCA_E_INVAL;
     *out = nullptr;
-    if (!d || d->N < 1 || d->N > 63 || d->n_static < 1 || d->n_dyn < 0 || d->n_dyn > OBCA_MAX_DYN ||
+    if (!d || d->N < 1 || d->N > 127 || d->n_static < 1 || d->n_dyn < 0 || d->n_dyn > OBCA_MAX_DYN ||
         d->n_static + d->n_dyn > OBCA_MAX_OBST || d->path_max < 2 || d->batch < 1 || d->max_steps < 1)
         return OBCA_E_INVAL;
     for (int i = 0; i < d->n_static; ++i)
