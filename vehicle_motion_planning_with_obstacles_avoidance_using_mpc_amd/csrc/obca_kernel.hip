@@ -103,8 +103,8 @@ struct Sh {
     double *Aobs, *bobs, *xref;
     double *Lall, *lall, *Sloc, *Y;
     double *Pk, *qk, *Kk, *kapk, *Mik;
-    double *FG, *Mall, *mall;
-    double *filt2;                           // second bank of the filter: 64 (theta, phi) pairs, entry i owned by lane i
+    double *X, *qt, *FG, *fv, *Z, *zv, *Mall, *mall;
+    double *red;
     int* offm;
 };
 
@@ -1131,7 +1131,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
         S.Lall = take(64 * N1); S.lall = take(8 * N1); S.Y = take(MW * 4 * np);
         S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
-        S.FG = take(48 * N1); S.Mall = take(64); S.mall = take(8); S.filt2 = take(128);
+        S.X = take(36); S.qt = take(6); S.FG = take(48 * N1); S.fv = take(6); S.Z = take(48); S.zv = take(6);
+        S.Mall = take(64); S.mall = take(8); S.red = take(8);
         S.offm = reinterpret_cast<int*>(take(8));
         S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
     }
@@ -1275,11 +1276,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     }
 
     // filter: one entry per lane
-    // filter: first 64 entries one per lane in registers, the next 64 in LDS (entry i read and pruned by lane i;
-    // theta = +inf marks an empty or pruned slot, which never blocks a trial point)
     bool f_valid = false;
     double f_th = 0.0, f_phi = 0.0;
-    S.filt2[2 * lane] = INFINITY; S.filt2[2 * lane + 1] = INFINITY;
     double theta_max = 0.0, theta_min = 0.0;
     double delta_w_last = 0.0, tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
     int acc_count = 0;
@@ -1337,7 +1335,6 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
                 mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, mu * sqrt(mu)));      // mu^theta_mu, theta_mu = 1.5
                 tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
                 f_valid = false;
-                S.filt2[2 * lane] = INFINITY; S.filt2[2 * lane + 1] = INFINITY;
             }
         }
         PROF(1)
@@ -1482,9 +1479,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
             bool ok = false;
             aug = false;
             const bool finite = isfinite(phi_t) && isfinite(th_t);
-            const bool blocked = (th_t >= theta_max) ||
-                                 (__any((f_valid && th_t >= f_th && phi_t >= f_phi) ||
-                                        (th_t >= S.filt2[2 * lane] && phi_t >= S.filt2[2 * lane + 1])) != 0);
+            const bool blocked = (th_t >= theta_max) || (__any(f_valid && th_t >= f_th && phi_t >= f_phi) != 0);
             if (finite && !blocked) {
                 const bool switching = dphi < 0.0 && alpha * dpow(-dphi, OBCA_S_PHI) > OBCA_DELTA * dpow(th, OBCA_S_THETA);
                 if (th <= theta_min && switching) {
@@ -1503,17 +1498,10 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         if (aug) {
             const double tn = (1.0 - OBCA_GAMMA_THETA) * th, pn = phi - OBCA_GAMMA_PHI * th;
             if (f_valid && f_th >= tn && f_phi >= pn) f_valid = false;          // dominated entries leave
-            if (S.filt2[2 * lane] >= tn && S.filt2[2 * lane + 1] >= pn) { S.filt2[2 * lane] = INFINITY; S.filt2[2 * lane + 1] = INFINITY; }
             const unsigned long long freem = __ballot(!f_valid);
-            if (freem != 0ull) {
-                const int slot = __ffsll((long long)freem) - 1;
-                if (lane == slot) { f_valid = true; f_th = tn; f_phi = pn; }
-            } else {                                                            // register bank full: LDS bank
-                const unsigned long long free2 = __ballot(S.filt2[2 * lane] == INFINITY);
-                if (free2 == 0ull) { status = OBCA_STATUS_NUMERIC; break; }
-                const int slot = __ffsll((long long)free2) - 1;
-                if (lane == slot) { S.filt2[2 * lane] = tn; S.filt2[2 * lane + 1] = pn; }
-            }
+            if (freem == 0ull) { status = OBCA_STATUS_NUMERIC; break; }
+            const int slot = __ffsll((long long)freem) - 1;
+            if (lane == slot) { f_valid = true; f_th = tn; f_phi = pn; }
         }
         // ---- accept ------------------------------------------------------------------------------------------
 #pragma unroll
