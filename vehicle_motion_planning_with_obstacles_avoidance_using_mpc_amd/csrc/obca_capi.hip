@@ -59,7 +59,7 @@ int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off)
     take(N1 * M * 2); take(N1 * M); take(3 * N1);
     take(64 * N1); take(8 * N1); take(MW * 4 * np);
     take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
-    take(36); take(6); take(48 * N1); take(6); take(48); take(6); take(64); take(8); take(8);
+    take(48 * N1); take(64); take(8);                          // FG, Mall, mall
     take(8);                 // offm
     inst_off = (int)t;
     take(OBCA_INST_DOUBLES);

@@ -103,8 +103,7 @@ struct Sh {
     double *Aobs, *bobs, *xref;
     double *Lall, *lall, *Sloc, *Y;
     double *Pk, *qk, *Kk, *kapk, *Mik;
-    double *X, *qt, *FG, *fv, *Z, *zv, *Mall, *mall;
-    double *red;
+    double *FG, *Mall, *mall;
     int* offm;
 };
 
@@ -1131,8 +1130,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
         S.Lall = take(64 * N1); S.lall = take(8 * N1); S.Y = take(MW * 4 * np);
         S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
-        S.X = take(36); S.qt = take(6); S.FG = take(48 * N1); S.fv = take(6); S.Z = take(48); S.zv = take(6);
-        S.Mall = take(64); S.mall = take(8); S.red = take(8);
+        S.FG = take(48 * N1); S.Mall = take(64); S.mall = take(8);
         S.offm = reinterpret_cast<int*>(take(8));
         S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
     }
