@@ -1471,7 +1471,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
                 double e1, e2;
                 rot_value(L, S.xt, S.ctt, S.stt, S.cct, pr, e1, e2);
                 th_t += fabs(e1) + fabs(e2);
-            }
+                S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;      // the current point's values are not needed any more;
+            }                                                      // the accepted trial's are the next iterate's
             th_t = wave_sum(th_t);
             phi_t = wave_sum(phi_t) + f_t;
             bool ok = false;
@@ -1542,20 +1543,17 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         fobj_prev = fobj;
         have_prev = true;
         PROF(8)
-        // ---- re-evaluate at the new iterate ------------------------------------------------------------------
-        eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
-        f = eval_objective<true>(L, S, in, S.x, sf, lane);
-        for (int r = lane; r < L.R; r += 64) S.tmp[r] = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
+        // ---- the new iterate IS the accepted trial point: its geometry (ctt/stt/cct), row values (tmp) and rotation
+        // residuals (crot) were evaluated by the line search; only the objective gradient is new ------------------
+        for (int k = lane; k <= L.N; k += 64) { S.ct[k] = S.ctt[k]; S.st[k] = S.stt[k]; }
+        for (int t = lane; t < 2 * L.npair; t += 64) S.cc[t] = S.cct[t];
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
             const int r = lane + 64 * j;
             if (r < L.R) W.g[j] = S.tmp[r];
         }
-        for (int pr = lane; pr < L.npair; pr += 64) {
-            double e1, e2;
-            rot_value(L, S.x, S.ct, S.st, S.cc, pr, e1, e2);
-            S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;
-        }
+        SYNC();
+        f = eval_objective<true>(L, S, in, S.x, sf, lane);
         SYNC();
         PROF(9)
     }
