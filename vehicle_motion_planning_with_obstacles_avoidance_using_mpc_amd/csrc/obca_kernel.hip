@@ -269,13 +269,7 @@ __device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, cons
             if (lane == 0) S.gf[L.iT()] = sf * gT;
         }
     }
-    if (GRAD) {
-        for (int k = 0; k <= L.N; ++k) {
-            const int w = L.M + 4 * L.nO;
-            for (int j = lane; j < w; j += 64) S.gf[L.il(k) + j] = 0.0;
-        }
-        SYNC();
-    }
+    if (GRAD) SYNC();             // the lambda / mu entries of gf are zero for good (set once at the start)
     return sf * f;
 }
 
@@ -1209,6 +1203,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     bool bad_bounds = false;
 
     // objective scaling: IPOPT's gradient rule applied to f + rho*sum(p+n)
+    for (int t = lane; t < L.n; t += 64) S.gf[t] = 0.0;        // the objective does not depend on lambda, mu
+    SYNC();
     eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
     double f = eval_objective<true>(L, S, in, S.x, 1.0, lane);
     {
@@ -1449,7 +1445,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
             for (int t = lane; t < L.n; t += 64) S.xt[t] = S.x[t] + alpha * S.dx[t];
             SYNC();
             eval_geom(L, S, S.xt, S.ctt, S.stt, S.cct, lane);
-            f_t = eval_objective<false>(L, S, in, S.xt, sf, lane);
+            f_t = eval_objective<true>(L, S, in, S.xt, sf, lane);     // gradient too: gf of the current point is spent
             double th_t = 0.0, phi_t = 0.0;
             for (int r = lane; r < L.R; r += 64) S.tmp[r] = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
 #pragma unroll
@@ -1552,8 +1548,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
             const int r = lane + 64 * j;
             if (r < L.R) W.g[j] = S.tmp[r];
         }
-        SYNC();
-        f = eval_objective<true>(L, S, in, S.x, sf, lane);
+        f = f_t;                  // objective and its gradient (gf) came with the accepted trial as well
         SYNC();
         PROF(9)
     }
