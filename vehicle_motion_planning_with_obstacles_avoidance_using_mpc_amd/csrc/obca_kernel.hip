@@ -469,6 +469,56 @@ __device__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double 
     return e;
 }
 
+// First evaluation of an iteration: the optimality error at mu = 0 (termination tests) and at the current mu (barrier
+// update) differ only in the complementarity term, and the constraint violation theta, the elastic sum and the largest
+// elastic variable read the same registers -- one pass over the rows instead of three.  nz / nrow (numbers of bound
+// multipliers and of rows) never change and are passed in.  th_lane carries the lane's rotation-row part of theta in.
+struct ErrFirst { Err e0, em; double th, pnsum, emax; };
+template <int RPL>
+__device__ ErrFirst ipm_errors_first(const Lay& L, const Sh& S, const Rows<RPL>& W, double mu, double rho, double rxmax,
+                                     double crotmax, double nusum, double th_lane, double nz, double nrow, int lane) {
+    double dual = 0.0, prim = 0.0, comp0 = 0.0, compm = 0.0, ysum = 0.0, zsum = 0.0, th = th_lane, pnsum = 0.0, emax = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        const int r = lane + 64 * j;
+        if (r < L.R) {
+            const double w = row_w(L, r);
+            const bool eq = row_iseq(L, r);
+            const double lo_ = S.Lb[r], up_ = S.Ub[r];
+            const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
+            const double s = W.s[j], y = W.y[j], p = W.p[j], n = W.n[j];
+            const double zL = hasL ? W.zL[j] : 0.0, zU = hasU ? W.zU[j] : 0.0, zp = W.zp[j], zn = W.zn[j];
+            if (!eq) dual = dmaxabs(dual, -y - zL + zU);
+            dual = dmaxabs(dual, rho - y - zp);
+            dual = dmaxabs(dual, rho + y - zn);
+            const double res = W.g[j] - (eq ? 0.0 : s) - p + n;
+            prim = dmaxabs(prim, res);
+            th += w * fabs(res);
+            pnsum += w * (p + n);
+            emax = fmax(emax, p + n);
+            comp0 = dmaxabs(comp0, p * zp); compm = dmaxabs(compm, p * zp - mu);
+            comp0 = dmaxabs(comp0, n * zn); compm = dmaxabs(compm, n * zn - mu);
+            if (hasL) { comp0 = dmaxabs(comp0, (s - lo_) * zL); compm = dmaxabs(compm, (s - lo_) * zL - mu); }
+            if (hasU) { comp0 = dmaxabs(comp0, (up_ - s) * zU); compm = dmaxabs(compm, (up_ - s) * zU - mu); }
+            ysum += w * fabs(y);
+            zsum += w * (zL + zU + zp + zn);
+        }
+    }
+    ErrFirst o;
+    dual = fmax(wave_max(dual), rxmax);
+    prim = fmax(wave_max(prim), crotmax);
+    comp0 = wave_max(comp0);
+    compm = wave_max(compm);
+    ysum = wave_sum(ysum) + nusum;
+    zsum = wave_sum(zsum);
+    o.th = wave_sum(th); o.pnsum = wave_sum(pnsum); o.emax = wave_max(emax);
+    const double sd = fmax(OBCA_S_MAX, (ysum + zsum) / (nrow + nz)) / OBCA_S_MAX;
+    const double sc = fmax(OBCA_S_MAX, zsum / nz) / OBCA_S_MAX;
+    o.e0.dual = dual; o.e0.prim = prim; o.e0.comp = comp0; o.e0.E = fmax(fmax(dual / sd, prim), comp0 / sc);
+    o.em.dual = dual; o.em.prim = prim; o.em.comp = compm; o.em.E = fmax(fmax(dual / sd, prim), compm / sc);
+    return o;
+}
+
 // linearisation of one row at the current iterate: inverse D's and residuals (IPOPT's Sigma + delta_w)
 struct Lin { double iDs, iDp, iDn, rs, rp, rn; };
 __device__ __forceinline__ Lin row_lin(double lo, double up, bool eq, double s, double p, double n, double y,
@@ -1269,6 +1319,21 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         SYNC();
     }
 
+    // constants of the error scaling: number of bound multipliers and of rows (Topt rows count N+1 times)
+    double cnt_nz = 0.0, cnt_rows = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        const int r = lane + 64 * j;
+        if (r < L.R) {
+            const double w = row_w(L, r);
+            const bool eq = row_iseq(L, r);
+            cnt_nz += w * (((!eq && S.Lb[r] > -INFINITY) ? 1.0 : 0.0) + ((!eq && S.Ub[r] < INFINITY) ? 1.0 : 0.0) + 2.0);
+            cnt_rows += w;
+        }
+    }
+    cnt_nz = wave_sum(cnt_nz);
+    cnt_rows = wave_sum(cnt_rows) + 2.0 * L.npair;
+
     // filter: one entry per lane
     bool f_valid = false;
     double f_th = 0.0, f_phi = 0.0;
@@ -1293,20 +1358,10 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         double rxmax = 0.0, crotmax = 0.0, nusum = 0.0, th = 0.0, pnsum = 0.0;
         for (int t = lane; t < L.n; t += 64) rxmax = dmaxabs(rxmax, S.bx[t]);
         for (int t = lane; t < 2 * L.npair; t += 64) { crotmax = dmaxabs(crotmax, S.crot[t]); nusum += fabs(S.nu[t]); th += fabs(S.crot[t]); }
-        double emax = 0.0;
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-            const int r = lane + 64 * j;
-            if (r < L.R) {
-                const double w = row_w(L, r);
-                th += w * fabs(W.g[j] - (row_iseq(L, r) ? 0.0 : W.s[j]) - W.p[j] + W.n[j]);
-                pnsum += w * (W.p[j] + W.n[j]);
-                emax = fmax(emax, W.p[j] + W.n[j]);
-            }
-        }
-        rxmax = wave_max(rxmax); crotmax = wave_max(crotmax); nusum = wave_sum(nusum); th = wave_sum(th);
-        pnsum = wave_sum(pnsum); elastic_max = wave_max(emax);
-        const Err e0 = ipm_errors<RPL>(L, S, W, 0.0, rho, rxmax, crotmax, nusum, lane);
+        rxmax = wave_max(rxmax); crotmax = wave_max(crotmax); nusum = wave_sum(nusum);
+        const ErrFirst ef = ipm_errors_first<RPL>(L, S, W, mu, rho, rxmax, crotmax, nusum, th, cnt_nz, cnt_rows, lane);
+        th = ef.th; pnsum = ef.pnsum; elastic_max = ef.emax;
+        const Err e0 = ef.e0;
         E0 = e0.E;
         if (it == 0) {
             theta_max = OBCA_THETA_MAX_FACT * fmax(1.0, th);
@@ -1323,8 +1378,10 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         // ---- barrier parameter ---------------------------------------------------------------------------
         {
             const double mu_floor = O.tol / (OBCA_KAPPA_EPS + 1.0);
+            bool first_mu = true;
             while (mu > mu_floor) {
-                const Err em = ipm_errors<RPL>(L, S, W, mu, rho, rxmax, crotmax, nusum, lane);
+                const Err em = first_mu ? ef.em : ipm_errors<RPL>(L, S, W, mu, rho, rxmax, crotmax, nusum, lane);
+                first_mu = false;
                 if (em.E > OBCA_KAPPA_EPS * mu) break;
                 mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, mu * sqrt(mu)));      // mu^theta_mu, theta_mu = 1.5
                 tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
