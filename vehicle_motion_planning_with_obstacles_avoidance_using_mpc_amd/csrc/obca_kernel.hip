@@ -1489,9 +1489,13 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         for (int t = lane; t < L.n; t += 64) dphi += S.gf[t] * S.dx[t];
         a_max = wave_min(a_max); a_z = wave_min(a_z); dphi = wave_sum(dphi); phi = wave_sum(phi) + f;
         double alpha_min;
+        // the two powers of the switching condition do not depend on the step length: once per iteration, not per trial
+        double pw_th = 0.0, pw_dphi = 1.0;
         if (dphi < 0.0) {
+            pw_th = dpow(th, OBCA_S_THETA);
+            pw_dphi = dpow(-dphi, OBCA_S_PHI);
             double c = fmin(OBCA_GAMMA_THETA, OBCA_GAMMA_PHI * th / (-dphi));
-            if (th <= theta_min) c = fmin(c, OBCA_DELTA * dpow(th, OBCA_S_THETA) / dpow(-dphi, OBCA_S_PHI));
+            if (th <= theta_min) c = fmin(c, OBCA_DELTA * pw_th / pw_dphi);
             alpha_min = OBCA_GAMMA_ALPHA * c;
         } else alpha_min = OBCA_GAMMA_ALPHA * OBCA_GAMMA_THETA;
         PROF(6)
@@ -1533,7 +1537,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
             const bool finite = isfinite(phi_t) && isfinite(th_t);
             const bool blocked = (th_t >= theta_max) || (__any(f_valid && th_t >= f_th && phi_t >= f_phi) != 0);
             if (finite && !blocked) {
-                const bool switching = dphi < 0.0 && alpha * dpow(-dphi, OBCA_S_PHI) > OBCA_DELTA * dpow(th, OBCA_S_THETA);
+                const bool switching = dphi < 0.0 && alpha * pw_dphi > OBCA_DELTA * pw_th;
                 if (th <= theta_min && switching) {
                     ok = phi_t <= phi + OBCA_ETA_PHI * alpha * dphi + 10.0 * 2.220446049250313e-16 * fabs(phi);
                 } else {
