@@ -121,10 +121,12 @@ int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
 int64_t obca_primal_size(const obca_dims* dims);
 int obca_set_warm_start(obca_handle* h, double* z, const int32_t* use, double mu_init);
 
-/* Kernel selection: 0 = auto (default; also env OBCA_MODE): the wave-per-instance kernel whenever the shape fits one CU's
- * LDS, else the lane-per-instance kernel; 1 = wave-per-instance (one wavefront per instance, working set in LDS);
- * 2 = lane-per-instance (64 instances per wavefront, working set in an HBM workspace owned by the handle; any shape,
- * e.g. N=20 with 5 obstacles).  Returns OBCA_E_LDS if mode 1 cannot hold the shape. */
+/* Kernel selection: 0 = auto (default; also env OBCA_MODE): one wavefront per instance when its rows fit the
+ * wavefront's registers (<= 384 rows) and its working set one CU's LDS; else four wavefronts per instance when the
+ * working set still fits the LDS (<= 768 rows, e.g. N = 20 with three obstacles); else the lane-per-instance kernel.
+ * 1 = one wavefront per instance; 2 = lane-per-instance (64 instances per wavefront, working set in an HBM workspace
+ * owned by the handle; any shape, e.g. N = 20 with five obstacles); 3 = four wavefronts per instance.
+ * Returns OBCA_E_LDS if mode 1 / 3 cannot hold the shape. */
 int obca_set_mode(obca_handle* h, int mode);
 
 /* Diagnostic: device buffer [max_batch,20] receiving per-phase shader-clock totals of each instance.

@@ -12,6 +12,7 @@
 extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A);
 extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A);
 extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A);
+extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A);          // four wavefronts per instance (obca_kernel_mw.hip)
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
 struct obca_handle {
@@ -20,8 +21,9 @@ struct obca_handle {
     int32_t offm[OBCA_MAX_OBST + 1];
     int64_t lds_bytes;
     double* prof;
-    int mode;                 /* 0 auto, 1 wave-per-instance (LDS), 2 lane-per-instance (HBM workspace) */
-    bool wave_ok;             /* the LDS kernel can hold this shape */
+    int mode;                 /* 0 auto, 1 wave-per-instance (LDS), 2 lane-per-instance (HBM workspace), 3 four waves per instance */
+    bool wave_ok;             /* the one-wavefront LDS kernel can hold this shape */
+    bool mw_ok;               /* the four-wavefront LDS kernel can hold this shape */
     double* warm_z;           /* obca_set_warm_start */
     const int32_t* warm_use;
     double warm_mu;
@@ -91,7 +93,14 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     }
     h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
     h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
+    h->mw_ok = !(h->lds_bytes + 64 > 160 * 1024 || h->R_max > 768);  // 256 threads x 3 rows; 32 B of static LDS
     if (hipSetDevice(d->device) != hipSuccess) { delete h; return OBCA_E_HIP; }
+    if (h->mw_ok && h->lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(obca_ipm_kernel_mw_r3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h->lds_bytes) != hipSuccess) {
+        delete h;
+        return OBCA_E_HIP;
+    }
     if (h->wave_ok && h->lds_bytes > 64 * 1024) {
         const void* fn = h->R_max <= 256   ? reinterpret_cast<const void*>(obca_ipm_kernel_r4)
                          : h->R_max <= 320 ? reinterpret_cast<const void*>(obca_ipm_kernel_r5)
@@ -120,8 +129,9 @@ extern "C" void obca_destroy(obca_handle* h) {
 }
 
 extern "C" int obca_set_mode(obca_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 2) return OBCA_E_INVAL;
+    if (!h || mode < 0 || mode > 3) return OBCA_E_INVAL;
     if (mode == 1 && !h->wave_ok) return OBCA_E_LDS;
+    if (mode == 3 && !h->mw_ok) return OBCA_E_LDS;
     h->mode = mode;
     return OBCA_OK;
 }
@@ -202,8 +212,15 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     // wave kernel (working set in LDS) whenever the shape fits one CU; the lane kernel (working set in an HBM
     // workspace, one instance per lane) takes the shapes beyond the LDS -- measured on MI355X it is latency bound
     // (every access is an L2/HBM round trip at one wave per SIMD) and 4-10x slower where both run
-    bool lane = h->mode == 2 || !h->wave_ok;
     if (h->mode == 1 && !h->wave_ok) return OBCA_E_LDS;
+    if (h->mode == 3 && !h->mw_ok) return OBCA_E_LDS;
+    // one wavefront per instance where the rows fit its registers; four wavefronts (one CU) per instance for bigger
+    // shapes that still fit the LDS; the lane kernel for everything else
+    const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
+    const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
+    if (mw) {
+        hipLaunchKernelGGL(obca_ipm_kernel_mw_r3, dim3(B), dim3(256), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+    } else
     if (!lane) {
         if (h->R_max <= 256)
             hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);

@@ -20,6 +20,15 @@
 
 #define SYNC() __syncthreads()
 
+// Threads per instance.  64 = one wavefront per instance (this file compiled as is).  csrc/obca_kernel_mw.hip includes
+// this file with OBCA_NT = 256: four wavefronts (one per SIMD of a CU) share one instance whose working set is too
+// large for one wavefront's registers / needs most of the CU's LDS (long horizons).  Every loop below strides by NT,
+// every reduction goes through red_* (wave-level for NT = 64, wave + LDS exchange otherwise), and the few places
+// where exactly 64 lanes play fixed roles (8x8 stage blocks, the filter) are confined to the first wavefront.
+#ifndef OBCA_NT
+#define OBCA_NT 64
+#endif
+
 #ifdef OBCA_PROFILE
 #define PROF_DECL long long prof_last = wall_clock64();
 #define PROF(i) { const long long t_ = wall_clock64(); prof_t[i] += t_ - prof_last; prof_last = t_; }
@@ -33,6 +42,7 @@ __device__ long long* prof_dummy;
 
 namespace {
 
+constexpr int NT = OBCA_NT;
 constexpr int MW = OBCA_MAX_EDGES + 6;      // local block width: lambda (<=4) + mu (4) + nu (2)
 constexpr int NW = OBCA_MAX_EDGES + 4;      // primal part of the local block
 
@@ -72,6 +82,28 @@ __device__ __forceinline__ double wave_sum(double v) { OBCA_ROW_REDUCE(op_add) r
 __device__ __forceinline__ double wave_max(double v) { OBCA_ROW_REDUCE(fmax) return fmax(fmax(r0, r1), fmax(r2, r3)); }
 __device__ __forceinline__ double wave_min(double v) { OBCA_ROW_REDUCE(fmin) return fmin(fmin(r0, r1), fmin(r2, r3)); }
 __device__ __forceinline__ int wave_or(int v) { return __any(v) ? 1 : 0; }
+
+// reductions over all NT threads of the instance; the result is identical in every thread
+#if OBCA_NT == 64
+__device__ __forceinline__ double red_sum(double v) { return wave_sum(v); }
+__device__ __forceinline__ double red_max(double v) { return wave_max(v); }
+__device__ __forceinline__ double red_min(double v) { return wave_min(v); }
+__device__ __forceinline__ int red_or(int v) { return wave_or(v); }
+#else
+__shared__ double g_red[OBCA_NT / 64];
+#define OBCA_BLOCK_REDUCE(WAVE_OP, COMBINE)                                \
+    const double w = WAVE_OP(v);                                           \
+    if ((threadIdx.x & 63) == 0) g_red[threadIdx.x >> 6] = w;              \
+    __syncthreads();                                                       \
+    double r = g_red[0];                                                   \
+    _Pragma("unroll") for (int i = 1; i < OBCA_NT / 64; ++i) r = COMBINE(r, g_red[i]); /* fixed order */ \
+    __syncthreads();                                                       \
+    return r;
+__device__ __forceinline__ double red_sum(double v) { OBCA_BLOCK_REDUCE(wave_sum, op_add) }
+__device__ __forceinline__ double red_max(double v) { OBCA_BLOCK_REDUCE(wave_max, fmax) }
+__device__ __forceinline__ double red_min(double v) { OBCA_BLOCK_REDUCE(wave_min, fmin) }
+__device__ __forceinline__ int red_or(int v) { return red_max(v ? 1.0 : 0.0) > 0.0 ? 1 : 0; }
+#endif
 
 // ---------------------------------------------------------------- instance layout
 struct Lay {
@@ -120,12 +152,12 @@ __device__ __forceinline__ bool row_soft(const Lay& L, int r) { return r < L.r_t
 // trig + c = A^T lambda for an iterate held in xv; results into ct/st/cc
 __device__ void eval_geom(const Lay& L, const Sh& S, const double* xv, double* ct, double* st, double* cc,
                           int lane) {
-    for (int k = lane; k <= L.N; k += 64) {
+    for (int k = lane; k <= L.N; k += NT) {
         const SinCos sc = dsincos(xv[L.ip(k) + 2]);
         ct[k] = sc.c;
         st[k] = sc.s;
     }
-    for (int pr = lane; pr < L.npair; pr += 64) {
+    for (int pr = lane; pr < L.npair; pr += NT) {
         const int k = pr / L.nO, i = pr - k * L.nO;
         const int o0 = S.offm[i], o1 = S.offm[i + 1];
         const double* lam = xv + L.il(k);
@@ -229,7 +261,7 @@ __device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, cons
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
     double part = 0.0, gT = 0.0;
-    for (int k = lane; k <= L.N; k += 64) {
+    for (int k = lane; k <= L.N; k += NT) {
         const double* pk = xv + L.ip(k);
         const double* W = (k < L.N) ? in.Q : in.P;
         double e[3], We[3];
@@ -261,11 +293,11 @@ __device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, cons
             if (GRAD) { S.gf[L.iu(k)] = sf * g0; S.gf[L.iu(k) + 1] = sf * g1; }
         }
     }
-    double f = wave_sum(part);
+    double f = red_sum(part);
     if (L.free_T) {
         f += (L.N + 1) * (10.0 * T + T * T);
         if (GRAD) {
-            gT = wave_sum(gT) + (L.N + 1) * (10.0 + 2.0 * T);
+            gT = red_sum(gT) + (L.N + 1) * (10.0 + 2.0 * T);
             if (lane == 0) S.gf[L.iT()] = sf * gT;
         }
     }
@@ -280,7 +312,7 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
     // poses and inputs
-    for (int t = lane; t < (L.N + 1) * 5; t += 64) {
+    for (int t = lane; t < (L.N + 1) * 5; t += NT) {
         const int k = t / 5, j = t - 5 * k;
         if (j >= 3 && k == L.N) continue;
         const double cs = S.ct[k], sn = S.st[k];
@@ -326,7 +358,7 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
         }
     }
     // lambda
-    for (int t = lane; t < (L.N + 1) * L.M; t += 64) {
+    for (int t = lane; t < (L.N + 1) * L.M; t += NT) {
         const int k = t / L.M, j = t - k * L.M;
         int i = 0;
         while (j >= S.offm[i + 1]) ++i;
@@ -342,7 +374,7 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
         out[L.il(k) + j] = v;
     }
     // mu
-    for (int t = lane; t < (L.N + 1) * 4 * L.nO; t += 64) {
+    for (int t = lane; t < (L.N + 1) * 4 * L.nO; t += NT) {
         const int w4 = 4 * L.nO, k = t / w4, q = t - k * w4, i = q >> 2, j = q & 3;
         const int pr = k * L.nO + i;
         const double sgn = (j < 2) ? 1.0 : -1.0;
@@ -354,7 +386,7 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
     // time scale
     if (L.free_T) {
         double part = 0.0;
-        for (int k = lane; k < L.N; k += 64) {
+        for (int k = lane; k < L.N; k += NT) {
             const double* u = xv + L.iu(k);
             const double* yd = ym + L.r_dyn + 3 * k;
             part -= in.Ts * (u[0] * S.ct[k] * yd[0] + u[0] * S.st[k] * yd[1] + u[1] * yd[2]);
@@ -363,7 +395,7 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
                 part -= ym[L.r_acc + 2 * k + c] * (prev - u[c]) / (T * h);
             }
         }
-        part = wave_sum(part);
+        part = red_sum(part);
         if (lane == 0) out[L.iT()] = S.gf[L.iT()] + part + (L.N + 1) * (ym[L.r_T] + ym[L.r_T + 1]);
     }
     SYNC();
@@ -432,7 +464,7 @@ __device__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double 
     double dual = 0.0, prim = 0.0, comp = 0.0, ysum = 0.0, zsum = 0.0, nz = 0.0, nrow = 0.0;
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
-        const int r = lane + 64 * j;
+        const int r = lane + NT * j;
         if (r < L.R) {
             const double w = row_w(L, r);
             const bool eq = row_iseq(L, r);
@@ -454,13 +486,13 @@ __device__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double 
             nrow += w;
         }
     }
-    dual = fmax(wave_max(dual), rxmax);
-    prim = fmax(wave_max(prim), crotmax);
-    comp = wave_max(comp);
-    ysum = wave_sum(ysum) + nusum;
-    zsum = wave_sum(zsum);
-    nz = wave_sum(nz);
-    nrow = wave_sum(nrow) + 2.0 * L.npair;
+    dual = fmax(red_max(dual), rxmax);
+    prim = fmax(red_max(prim), crotmax);
+    comp = red_max(comp);
+    ysum = red_sum(ysum) + nusum;
+    zsum = red_sum(zsum);
+    nz = red_sum(nz);
+    nrow = red_sum(nrow) + 2.0 * L.npair;
     const double sd = fmax(OBCA_S_MAX, (ysum + zsum) / (nrow + nz)) / OBCA_S_MAX;
     const double sc = fmax(OBCA_S_MAX, zsum / nz) / OBCA_S_MAX;
     Err e;
@@ -480,7 +512,7 @@ __device__ ErrFirst ipm_errors_first(const Lay& L, const Sh& S, const Rows<RPL>&
     double dual = 0.0, prim = 0.0, comp0 = 0.0, compm = 0.0, ysum = 0.0, zsum = 0.0, th = th_lane, pnsum = 0.0, emax = 0.0;
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
-        const int r = lane + 64 * j;
+        const int r = lane + NT * j;
         if (r < L.R) {
             const double w = row_w(L, r);
             const bool eq = row_iseq(L, r);
@@ -505,13 +537,13 @@ __device__ ErrFirst ipm_errors_first(const Lay& L, const Sh& S, const Rows<RPL>&
         }
     }
     ErrFirst o;
-    dual = fmax(wave_max(dual), rxmax);
-    prim = fmax(wave_max(prim), crotmax);
-    comp0 = wave_max(comp0);
-    compm = wave_max(compm);
-    ysum = wave_sum(ysum) + nusum;
-    zsum = wave_sum(zsum);
-    o.th = wave_sum(th); o.pnsum = wave_sum(pnsum); o.emax = wave_max(emax);
+    dual = fmax(red_max(dual), rxmax);
+    prim = fmax(red_max(prim), crotmax);
+    comp0 = red_max(comp0);
+    compm = red_max(compm);
+    ysum = red_sum(ysum) + nusum;
+    zsum = red_sum(zsum);
+    o.th = red_sum(th); o.pnsum = red_sum(pnsum); o.emax = red_max(emax);
     const double sd = fmax(OBCA_S_MAX, (ysum + zsum) / (nrow + nz)) / OBCA_S_MAX;
     const double sc = fmax(OBCA_S_MAX, zsum / nz) / OBCA_S_MAX;
     o.e0.dual = dual; o.e0.prim = prim; o.e0.comp = comp0; o.e0.E = fmax(fmax(dual / sd, prim), comp0 / sc);
@@ -557,7 +589,7 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts, ih2 = 1.0 / (h * h);
     double HTT = 0.0;
-    for (int k = lane; k <= L.N; k += 64) {
+    for (int k = lane; k <= L.N; k += NT) {
         // the stage block is accumulated in registers (read-modify-write through LDS serialised ~100 round trips)
         double Hpp[3][3], Huu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, Cpu[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
         double hpu = 0.0, hpT = 0.0, huT[2] = {0.0, 0.0};
@@ -671,7 +703,7 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
         lv[3] = 0.0; lv[4] = 0.0; lv[5] = 0.0; lv[6] = lu0; lv[7] = lu1;
     }
     if (L.free_T) {
-        HTT = wave_sum(HTT);
+        HTT = red_sum(HTT);
         if (lane == 0) {
             const double w = (double)(L.N + 1);
             HTT += sf * 2.0 * w + dw * w + w * (S.Einv[L.r_T] + S.Einv[L.r_T + 1]);
@@ -694,7 +726,7 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
 #endif
     // TWO lanes per pair: both factor the block (registers), each solves two of the four right-hand sides
     // [G_x G_y | G_theta rloc] and produces the matching columns of Y and of the Schur complement G'Y.
-    for (int w = lane; w < 2 * L.npair; w += 64) {
+    for (int w = lane; w < 2 * L.npair; w += NT) {
         const int pr = w >> 1;
         const bool hi = (w & 1) != 0;
         const int k = pr / L.nO, i = pr - k * L.nO;
@@ -831,7 +863,7 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
     }
     SYNC();
     // fold the Schur complements into the stage blocks
-    for (int k = lane; k <= L.N; k += 64) {
+    for (int k = lane; k <= L.N; k += NT) {
         double* H = S.Lall + 64 * k;
         double* lv = S.lall + 8 * k;
         for (int i = 0; i < L.nO; ++i) {
@@ -843,7 +875,7 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
         }
     }
     SYNC();
-    return wave_or(bad);
+    return red_or(bad);
 }
 
 // (I + Ppp E)^-1 by LU without pivoting; pivots equal those of I + E^1/2 Ppp E^1/2
@@ -943,7 +975,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     const double h = T * in.Ts;
     int bad = 0;
     // [F G] of every stage (6 x 8 each) and the terminal value function, one phase
-    for (int t = lane; t < 48 * L.N; t += 64) {
+    for (int t = lane; t < 48 * L.N; t += NT) {
         const int k = t / 48, e = t - 48 * k, a = e >> 3, b = e & 7;
         const double cs = S.ct[k], sn = S.st[k];
         const double* u = xv + L.iu(k);
@@ -980,7 +1012,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { E[j] = 1.0 / S.Einv[L.r_dyn + 3 * k + j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
         bad |= soft_min_regs(S.Pk + 36 * (k + 1), S.qk + 6 * (k + 1), E, X, qt, Mi);
-        {
+        if (NT == 64 || lane < 64) {
             const int a = lane >> 3, b = lane & 7;
             const double* FGk = S.FG + 48 * k;
             double fa[6], fb[6];
@@ -1030,7 +1062,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         }
         SYNC();
         RPROF(14)
-        if (wave_or(bad)) return 1;         // wrong-sign pivot: the attempt is over, no need to finish the sweep
+        if (red_or(bad)) return 1;         // wrong-sign pivot: the attempt is over, no need to finish the sweep
     }
     // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
     double E0[3], g0[3], X[36], qt[6], Mi0[9];
@@ -1038,7 +1070,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     for (int j = 0; j < 3; ++j) { E0[j] = 1.0 / S.Einv[L.r_init + j]; g0[j] = S.gh[L.r_init + j]; }
     bad |= soft_min_regs(S.Pk, S.qk, E0, X, qt, Mi0);
     if (L.free_T && !(X[35] > 0.0)) bad = 1;
-    bad = wave_or(bad);
+    bad = red_or(bad);
     RPROF(15)
     if (bad) return 1;
     // ---- forward pass: every lane carries the (tiny) state redundantly, lane 0 stores
@@ -1111,7 +1143,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     SYNC();
     RPROF(16)
     // local recovery: [dw; dnu] = Y_r - Y_G dp_k
-    for (int pr = lane; pr < L.npair; pr += 64) {
+    for (int pr = lane; pr < L.npair; pr += NT) {
         const int k = pr / L.nO, i = pr - k * L.nO;
         const int o0 = S.offm[i], m = S.offm[i + 1] - o0;
         const double* Yo = S.Y + (size_t)pr * (MW * 4);
@@ -1200,14 +1232,14 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     {
         const int N1 = L.N + 1;
         const double* xr = A.xref + (size_t)inst * 3 * N1;
-        for (int t = lane; t < 3 * N1; t += 64) S.xref[t] = xr[t];
+        for (int t = lane; t < 3 * N1; t += NT) S.xref[t] = xr[t];
         const double* Ag = A.A + (size_t)inst * N1 * L.M * 2;
         const double* bg = A.b + (size_t)inst * N1 * L.M;
-        for (int t = lane; t < N1 * L.M * 2; t += 64) {
+        for (int t = lane; t < N1 * L.M * 2; t += NT) {
             const int k = t / (2 * L.M), q = t - k * 2 * L.M;
             S.Aobs[t] = Ag[(size_t)(L.variant == 4 ? 0 : k) * L.M * 2 + q];     // q5: mpc4 reads step 0 only
         }
-        for (int t = lane; t < N1 * L.M; t += 64) {
+        for (int t = lane; t < N1 * L.M; t += NT) {
             const int k = t / L.M, q = t - k * L.M;
             S.bobs[t] = bg[(size_t)(L.variant == 4 ? 0 : k) * L.M + q];
         }
@@ -1228,22 +1260,22 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     if (warm) {
         const double* zp = A.warm_z + (size_t)inst * A.n_max;
         const int blk = L.NS - 2;                              // pose, lambda, mu of a stage (inputs handled apart)
-        for (int t = lane; t < (L.N + 1) * blk; t += 64) {
+        for (int t = lane; t < (L.N + 1) * blk; t += NT) {
             const int k = t / blk, q = t - k * blk;
             const int ks = k < L.N ? k + 1 : L.N;
             const int dst = (q < 3 ? L.ip(k) + q : L.il(k) + (q - 3));
             const int src = (q < 3 ? L.ip(ks) + q : L.il(ks) + (q - 3));
             S.x[dst] = zp[src];
         }
-        for (int t = lane; t < 2 * L.N; t += 64) {
+        for (int t = lane; t < 2 * L.N; t += NT) {
             const int k = t >> 1, j = t & 1;
             S.x[L.iu(k) + j] = zp[L.iu(k + 1 < L.N ? k + 1 : L.N - 1) + j];
         }
         if (L.free_T && lane == 0) S.x[L.iT()] = zp[L.iT()];
     } else {
-        for (int t = lane; t < L.n; t += 64) S.x[t] = 0.0;
+        for (int t = lane; t < L.n; t += NT) S.x[t] = 0.0;
     }
-    for (int t = lane; t < 2 * L.npair; t += 64) S.nu[t] = 0.0;
+    for (int t = lane; t < 2 * L.npair; t += NT) S.nu[t] = 0.0;
     SYNC();
     if (!warm && L.free_T && lane == 0) S.x[L.iT()] = 1.0;
     SYNC();
@@ -1253,14 +1285,14 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     bool bad_bounds = false;
 
     // objective scaling: IPOPT's gradient rule applied to f + rho*sum(p+n)
-    for (int t = lane; t < L.n; t += 64) S.gf[t] = 0.0;        // the objective does not depend on lambda, mu
+    for (int t = lane; t < L.n; t += NT) S.gf[t] = 0.0;        // the objective does not depend on lambda, mu
     SYNC();
     eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
     double f = eval_objective<true>(L, S, in, S.x, 1.0, lane);
     {
         double gm = 0.0;
-        for (int t = lane; t < L.n; t += 64) gm = dmaxabs(gm, S.gf[t]);
-        gm = fmax(wave_max(gm), O.rho);
+        for (int t = lane; t < L.n; t += NT) gm = dmaxabs(gm, S.gf[t]);
+        gm = fmax(red_max(gm), O.rho);
         sf = (gm > OBCA_MAX_GRADIENT) ? OBCA_MAX_GRADIENT / gm : 1.0;
         rho = O.rho * sf;
     }
@@ -1273,7 +1305,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         int bb = 0;
         // heavy per-row code (the row-type switch) runs in rolled loops that stage through LDS; the unrolled
         // register loops below only do arithmetic -- unrolling the switch RPL times exploded register pressure
-        for (int r = lane; r < L.R; r += 64) {
+        for (int r = lane; r < L.R; r += NT) {
             double lo, up;
             row_bounds(L, in, r, lo, up);
             S.Lb[r] = lo; S.Ub[r] = up;
@@ -1281,7 +1313,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         }
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
-            const int r = lane + 64 * j;
+            const int r = lane + NT * j;
             W.s[j] = 0.0; W.p[j] = 1.0; W.n[j] = 1.0; W.y[j] = 0.0;
             W.zL[j] = 0.0; W.zU[j] = 0.0; W.zp[j] = 1.0; W.zn[j] = 1.0; W.g[j] = 0.0; W.dy[j] = 0.0;
             W.iDs[j] = 0.0; W.iDp[j] = 1.0; W.iDn[j] = 1.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
@@ -1310,8 +1342,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
                 S.y[r] = W.y[j];
             }
         }
-        bad_bounds = wave_or(bb) != 0;
-        for (int pr = lane; pr < L.npair; pr += 64) {
+        bad_bounds = red_or(bb) != 0;
+        for (int pr = lane; pr < L.npair; pr += NT) {
             double e1, e2;
             rot_value(L, S.x, S.ct, S.st, S.cc, pr, e1, e2);
             S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;
@@ -1323,7 +1355,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     double cnt_nz = 0.0, cnt_rows = 0.0;
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
-        const int r = lane + 64 * j;
+        const int r = lane + NT * j;
         if (r < L.R) {
             const double w = row_w(L, r);
             const bool eq = row_iseq(L, r);
@@ -1331,8 +1363,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
             cnt_rows += w;
         }
     }
-    cnt_nz = wave_sum(cnt_nz);
-    cnt_rows = wave_sum(cnt_rows) + 2.0 * L.npair;
+    cnt_nz = red_sum(cnt_nz);
+    cnt_rows = red_sum(cnt_rows) + 2.0 * L.npair;
 
     // filter: one entry per lane
     bool f_valid = false;
@@ -1356,9 +1388,9 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         // ---- gradient of the Lagrangian and optimality error ------------------------------------------
         gather_grad(L, S, in, S.y, S.bx, lane);                    // bx doubles as scratch for grad_x L here
         double rxmax = 0.0, crotmax = 0.0, nusum = 0.0, th = 0.0, pnsum = 0.0;
-        for (int t = lane; t < L.n; t += 64) rxmax = dmaxabs(rxmax, S.bx[t]);
-        for (int t = lane; t < 2 * L.npair; t += 64) { crotmax = dmaxabs(crotmax, S.crot[t]); nusum += fabs(S.nu[t]); th += fabs(S.crot[t]); }
-        rxmax = wave_max(rxmax); crotmax = wave_max(crotmax); nusum = wave_sum(nusum);
+        for (int t = lane; t < L.n; t += NT) rxmax = dmaxabs(rxmax, S.bx[t]);
+        for (int t = lane; t < 2 * L.npair; t += NT) { crotmax = dmaxabs(crotmax, S.crot[t]); nusum += fabs(S.nu[t]); th += fabs(S.crot[t]); }
+        rxmax = red_max(rxmax); crotmax = red_max(crotmax); nusum = red_sum(nusum);
         const ErrFirst ef = ipm_errors_first<RPL>(L, S, W, mu, rho, rxmax, crotmax, nusum, th, cnt_nz, cnt_rows, lane);
         th = ef.th; pnsum = ef.pnsum; elastic_max = ef.emax;
         const Err e0 = ef.e0;
@@ -1400,7 +1432,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         for (;;) {
 #pragma unroll
             for (int j = 0; j < RPL; ++j) {
-                const int r = lane + 64 * j;
+                const int r = lane + NT * j;
                 if (r < L.R) {
                     const bool eq = row_iseq(L, r);
                     const double y = W.y[j];
@@ -1442,11 +1474,11 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         if (delta_w > 0.0) delta_w_last = delta_w;
         // ---- row steps, step lengths, directional derivative -----------------------------------------------
         double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0;
-        for (int r = lane; r < L.R; r += 64)
+        for (int r = lane; r < L.R; r += NT)
             S.tmp[r] = row_soft(L, r) ? S.dy[r] : (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r];
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
-            const int r = lane + 64 * j;
+            const int r = lane + NT * j;
             if (r < L.R) {
                 const bool eq = row_iseq(L, r);
                 const double lo_ = S.Lb[r], up_ = S.Ub[r];
@@ -1486,8 +1518,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
                 dphi += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
             }
         }
-        for (int t = lane; t < L.n; t += 64) dphi += S.gf[t] * S.dx[t];
-        a_max = wave_min(a_max); a_z = wave_min(a_z); dphi = wave_sum(dphi); phi = wave_sum(phi) + f;
+        for (int t = lane; t < L.n; t += NT) dphi += S.gf[t] * S.dx[t];
+        a_max = red_min(a_max); a_z = red_min(a_z); dphi = red_sum(dphi); phi = red_sum(phi) + f;
         double alpha_min;
         // the two powers of the switching condition do not depend on the step length: once per iteration, not per trial
         double pw_th = 0.0, pw_dphi = 1.0;
@@ -1503,15 +1535,15 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         double alpha = a_max, f_t = f;
         bool accepted = false, aug = false;
         for (;;) {
-            for (int t = lane; t < L.n; t += 64) S.xt[t] = S.x[t] + alpha * S.dx[t];
+            for (int t = lane; t < L.n; t += NT) S.xt[t] = S.x[t] + alpha * S.dx[t];
             SYNC();
             eval_geom(L, S, S.xt, S.ctt, S.stt, S.cct, lane);
             f_t = eval_objective<true>(L, S, in, S.xt, sf, lane);     // gradient too: gf of the current point is spent
             double th_t = 0.0, phi_t = 0.0;
-            for (int r = lane; r < L.R; r += 64) S.tmp[r] = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
+            for (int r = lane; r < L.R; r += NT) S.tmp[r] = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
 #pragma unroll
             for (int j = 0; j < RPL; ++j) {
-                const int r = lane + 64 * j;
+                const int r = lane + NT * j;
                 if (r < L.R) {
                     const bool eq = row_iseq(L, r);
                     const double dy = W.dy[j], w = row_w(L, r);
@@ -1524,18 +1556,22 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
                     phi_t += w * row_barrier(lo_, up_, eq, st, pt, nt, mu, rho);
                 }
             }
-            for (int pr = lane; pr < L.npair; pr += 64) {
+            for (int pr = lane; pr < L.npair; pr += NT) {
                 double e1, e2;
                 rot_value(L, S.xt, S.ctt, S.stt, S.cct, pr, e1, e2);
                 th_t += fabs(e1) + fabs(e2);
                 S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;      // the current point's values are not needed any more;
             }                                                      // the accepted trial's are the next iterate's
-            th_t = wave_sum(th_t);
-            phi_t = wave_sum(phi_t) + f_t;
+            th_t = red_sum(th_t);
+            phi_t = red_sum(phi_t) + f_t;
             bool ok = false;
             aug = false;
             const bool finite = isfinite(phi_t) && isfinite(th_t);
+#if OBCA_NT == 64
             const bool blocked = (th_t >= theta_max) || (__any(f_valid && th_t >= f_th && phi_t >= f_phi) != 0);
+#else               // the 64 filter entries live in the first wavefront
+            const bool blocked = (th_t >= theta_max) || red_or(lane < 64 && f_valid && th_t >= f_th && phi_t >= f_phi);
+#endif
             if (finite && !blocked) {
                 const bool switching = dphi < 0.0 && alpha * pw_dphi > OBCA_DELTA * pw_th;
                 if (th <= theta_min && switching) {
@@ -1553,16 +1589,27 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         if (!accepted) { status = OBCA_STATUS_LINESEARCH; break; }
         if (aug) {
             const double tn = (1.0 - OBCA_GAMMA_THETA) * th, pn = phi - OBCA_GAMMA_PHI * th;
+#if OBCA_NT == 64
             if (f_valid && f_th >= tn && f_phi >= pn) f_valid = false;          // dominated entries leave
             const unsigned long long freem = __ballot(!f_valid);
             if (freem == 0ull) { status = OBCA_STATUS_NUMERIC; break; }
             const int slot = __ffsll((long long)freem) - 1;
             if (lane == slot) { f_valid = true; f_th = tn; f_phi = pn; }
+#else
+            int full = 0;
+            if (lane < 64) {                                                    // whole first wavefront, uniform branch
+                if (f_valid && f_th >= tn && f_phi >= pn) f_valid = false;
+                const unsigned long long freem = __ballot(!f_valid);
+                if (freem == 0ull) full = 1;
+                else if (lane == __ffsll((long long)freem) - 1) { f_valid = true; f_th = tn; f_phi = pn; }
+            }
+            if (red_or(full)) { status = OBCA_STATUS_NUMERIC; break; }
+#endif
         }
         // ---- accept ------------------------------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
-            const int r = lane + 64 * j;
+            const int r = lane + NT * j;
             if (r < L.R) {
                 const bool eq = row_iseq(L, r);
                 const double lo_ = S.Lb[r], up_ = S.Ub[r];
@@ -1594,19 +1641,19 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
                 S.y[r] = W.y[j];
             }
         }
-        for (int t = lane; t < 2 * L.npair; t += 64) S.nu[t] += alpha * S.dnu[t];
-        for (int t = lane; t < L.n; t += 64) S.x[t] = S.xt[t];
+        for (int t = lane; t < 2 * L.npair; t += NT) S.nu[t] += alpha * S.dnu[t];
+        for (int t = lane; t < L.n; t += NT) S.x[t] = S.xt[t];
         SYNC();
         fobj_prev = fobj;
         have_prev = true;
         PROF(8)
         // ---- the new iterate IS the accepted trial point: its geometry (ctt/stt/cct), row values (tmp) and rotation
         // residuals (crot) were evaluated by the line search; only the objective gradient is new ------------------
-        for (int k = lane; k <= L.N; k += 64) { S.ct[k] = S.ctt[k]; S.st[k] = S.stt[k]; }
-        for (int t = lane; t < 2 * L.npair; t += 64) S.cc[t] = S.cct[t];
+        for (int k = lane; k <= L.N; k += NT) { S.ct[k] = S.ctt[k]; S.st[k] = S.stt[k]; }
+        for (int t = lane; t < 2 * L.npair; t += NT) S.cc[t] = S.cct[t];
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
-            const int r = lane + 64 * j;
+            const int r = lane + NT * j;
             if (r < L.R) W.g[j] = S.tmp[r];
         }
         f = f_t;                  // objective and its gradient (gf) came with the accepted trial as well
@@ -1622,15 +1669,15 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
 
     if (A.warm_z != nullptr && (status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE)) {
         double* zp = A.warm_z + (size_t)inst * A.n_max;        // kept for the next solve of this instance
-        for (int t = lane; t < L.n; t += 64) zp[t] = S.x[t];
+        for (int t = lane; t < L.n; t += NT) zp[t] = S.x[t];
     }
     // ---- outputs (last iterate on failure, like the reference's except-branch) --------------------------------
     {
         const int N1 = L.N + 1;
         double* xo = A.xopt + (size_t)inst * 3 * N1;
         double* uo = A.uopt + (size_t)inst * 2 * L.N;
-        for (int t = lane; t < 3 * N1; t += 64) { const int j = t / N1, k = t - j * N1; xo[t] = S.x[L.ip(k) + j]; }
-        for (int t = lane; t < 2 * L.N; t += 64) { const int j = t / L.N, k = t - j * L.N; uo[t] = S.x[L.iu(k) + j]; }
+        for (int t = lane; t < 3 * N1; t += NT) { const int j = t / N1, k = t - j * N1; xo[t] = S.x[L.ip(k) + j]; }
+        for (int t = lane; t < 2 * L.N; t += NT) { const int j = t / L.N, k = t - j * L.N; uo[t] = S.x[L.iu(k) + j]; }
         if (lane == 0) {
             A.ts_opt[inst] = L.free_T ? S.x[L.iT()] * in.Ts : in.Ts;
             A.status[inst] = status;
@@ -1644,6 +1691,7 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
 }
 
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
+#if OBCA_NT == 64
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A) { obca_ipm_body<4>(A, blockIdx.x); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A) { obca_ipm_body<5>(A, blockIdx.x); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A) { obca_ipm_body<6>(A, blockIdx.x); }
@@ -1693,3 +1741,8 @@ extern "C" __global__ void __launch_bounds__(64)
 obca_rollout_fused_kernel_r6(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
     rollout_fused_body<6>(*Dp, launches, n_steps);
 }
+
+#else
+// four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows)
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A) { obca_ipm_body<3>(A, blockIdx.x); }
+#endif

@@ -84,10 +84,11 @@ class BatchSolver:
         if mode is not None:
             self.set_mode(mode)
 
-    MODES = {"auto": 0, "wave": 1, "lane": 2}
+    MODES = {"auto": 0, "wave": 1, "lane": 2, "multiwave": 3}
 
     def set_mode(self, mode):
-        """'auto' | 'wave' (one wavefront per instance, LDS) | 'lane' (64 instances per wavefront, HBM workspace)"""
+        """'auto' | 'wave' (one wavefront per instance, LDS) | 'multiwave' (four wavefronts per instance, LDS) |
+        'lane' (64 instances per wavefront, HBM workspace)"""
         _lib.check(self.lib.obca_set_mode(self._h, self.MODES.get(mode, mode)))
 
     def close(self):
