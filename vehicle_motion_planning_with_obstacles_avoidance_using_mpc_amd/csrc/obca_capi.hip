@@ -13,6 +13,7 @@ extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A);
 extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A);
 extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A);
 extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A);          // four wavefronts per instance (obca_kernel_mw.hip)
+extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A);
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
 struct obca_handle {
@@ -53,15 +54,19 @@ int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off)
     R_max = 3 + 3 * N + 3 + 2 * N1 + 2 * N + 2 * N + 2 + 2 * np + N1 * M + N1 * 4 * nO;
     int64_t t = 0;
     auto take = [&](int64_t c) { t += (c + 1) & ~int64_t(1); };
-    for (int i = 0; i < 5; ++i) take(n_max);                    // x, xt, dx, gf, bx
-    for (int i = 0; i < 7; ++i) take(R_max);                    // y, Einv, yhat, gh, tmp, Lb, Ub
+    for (int i = 0; i < 4; ++i) take(n_max);                    // x, dx, gf, bx
+    for (int i = 0; i < 6; ++i) take(R_max);                    // y, Einv, yhat, gh, Lb, Ub
     take(3 * N1 + 3);                                           // dy of the soft rows
     take(N1); take(N1); take(2 * np); take(N1); take(N1); take(2 * np);
     take(2 * np); take(2 * np); take(2 * np);
     take(N1 * M * 2); take(N1 * M); take(3 * N1);
-    take(64 * N1); take(8 * N1); take(MW * 4 * np);
+    take(64 * N1); take(8 * N1);
+    {
+        const int64_t nx = (n_max + 1) & ~1, nr = (R_max + 1) & ~1, ny = (int64_t)MW * 4 * np;
+        take(ny > nx + nr ? ny : nx + nr);                      // Y, shared with xt and tmp
+    }
     take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
-    take(48 * N1); take(64); take(8);                          // FG, Mall, mall
+    take(48); take(64); take(8);                               // FG (one stage), Mall, mall
     take(8);                 // offm
     inst_off = (int)t;
     take(OBCA_INST_DOUBLES);
@@ -93,11 +98,12 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     }
     h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
     h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
-    h->mw_ok = !(h->lds_bytes + 64 > 160 * 1024 || h->R_max > 768);  // 256 threads x 3 rows; 32 B of static LDS
+    h->mw_ok = !(h->lds_bytes + 64 > 160 * 1024 || h->R_max > 1280); // 256 threads x 3 or 5 rows; 32 B of static LDS
     if (hipSetDevice(d->device) != hipSuccess) { delete h; return OBCA_E_HIP; }
     if (h->mw_ok && h->lds_bytes > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(obca_ipm_kernel_mw_r3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)h->lds_bytes) != hipSuccess) {
+        hipFuncSetAttribute(h->R_max <= 768 ? reinterpret_cast<const void*>(obca_ipm_kernel_mw_r3)
+                                            : reinterpret_cast<const void*>(obca_ipm_kernel_mw_r5),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         delete h;
         return OBCA_E_HIP;
     }
@@ -219,7 +225,8 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw) {
-        hipLaunchKernelGGL(obca_ipm_kernel_mw_r3, dim3(B), dim3(256), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+        hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
+                           (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
     } else
     if (!lane) {
         if (h->R_max <= 256)

@@ -956,6 +956,28 @@ __device__ __forceinline__ int soft_min_regs(const double* Pl, const double* ql,
     return bad;
 }
 
+// entry e = 8 a + b of the stage's [F G] = d xi_{k+1} / d (xi_k, du_k), xi = (dp, du_prev, dT): rows 0-2 the pose
+// update p + h (v cos, v sin, w) (column 5: its T-derivative), rows 3-4 pick du_k, row 5 carries dT.  Only ONE
+// stage's 6 x 8 block is kept in LDS: stage k-1's is written while phase B of stage k runs.
+__device__ __forceinline__ double fg_entry(const Lay& L, const Sh& S, const Inst& in, const double* xv, double h, int k, int e) {
+    const int a = e >> 3, b = e & 7;
+    const double cs = S.ct[k], sn = S.st[k];
+    const double* u = xv + L.iu(k);
+    double v = 0.0;
+    if (a < 3) {
+        if (b < 3) v = (a == b) ? 1.0 : 0.0;
+        if (b == 2) { if (a == 0) v = -h * u[0] * sn; else if (a == 1) v = h * u[0] * cs; }
+        if (b == 5 && L.free_T) v = in.Ts * ((a == 0) ? u[0] * cs : (a == 1) ? u[0] * sn : u[1]);
+        if (b == 6) v = (a == 0) ? h * cs : (a == 1) ? h * sn : 0.0;
+        if (b == 7) v = (a == 2) ? h : 0.0;
+    } else if (a < 5) {
+        v = (b == 6 + (a - 3)) ? 1.0 : 0.0;
+    } else {
+        v = (b == 5) ? 1.0 : 0.0;
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------- level 2: Riccati sweep + forward pass
 // Two LDS round trips per stage: (A) every lane rebuilds P~ in registers and produces ONE entry of the 8x8
 // stage matrix Mall = Lall + [F G]' P~ [F G]; (B) every lane inverts the 2x2 input block and produces one entry
@@ -974,25 +996,8 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
     int bad = 0;
-    // [F G] of every stage (6 x 8 each) and the terminal value function, one phase
-    for (int t = lane; t < 48 * L.N; t += NT) {
-        const int k = t / 48, e = t - 48 * k, a = e >> 3, b = e & 7;
-        const double cs = S.ct[k], sn = S.st[k];
-        const double* u = xv + L.iu(k);
-        double v = 0.0;
-        if (a < 3) {
-            if (b < 3) v = (a == b) ? 1.0 : 0.0;
-            if (b == 2) { if (a == 0) v = -h * u[0] * sn; else if (a == 1) v = h * u[0] * cs; }
-            if (b == 5 && L.free_T) v = in.Ts * ((a == 0) ? u[0] * cs : (a == 1) ? u[0] * sn : u[1]);
-            if (b == 6) v = (a == 0) ? h * cs : (a == 1) ? h * sn : 0.0;
-            if (b == 7) v = (a == 2) ? h : 0.0;
-        } else if (a < 5) {
-            v = (b == 6 + (a - 3)) ? 1.0 : 0.0;
-        } else {
-            v = (b == 5) ? 1.0 : 0.0;
-        }
-        S.FG[t] = v;
-    }
+    // [F G] of the first stage of the sweep, and the terminal value function
+    for (int t = lane; t < 48; t += NT) S.FG[t] = fg_entry(L, S, in, xv, h, L.N - 1, t);
     {
         double* PN = S.Pk + 36 * L.N;
         double* qN = S.qk + 6 * L.N;
@@ -1014,10 +1019,9 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         bad |= soft_min_regs(S.Pk + 36 * (k + 1), S.qk + 6 * (k + 1), E, X, qt, Mi);
         if (NT == 64 || lane < 64) {
             const int a = lane >> 3, b = lane & 7;
-            const double* FGk = S.FG + 48 * k;
             double fa[6], fb[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) { fa[c] = FGk[8 * c + a]; fb[c] = FGk[8 * c + b]; }
+            for (int c = 0; c < 6; ++c) { fa[c] = S.FG[8 * c + a]; fb[c] = S.FG[8 * c + b]; }
             double v = S.Lall[64 * k + lane];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
@@ -1060,6 +1064,8 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
                 if (a == 0) { S.kapk[2 * k] = k0; S.kapk[2 * k + 1] = k1; }
             }
         }
+        if (k > 0)                          // phase A of this stage is over: its [F G] can make room for the next one
+            for (int t = lane; t < 48; t += NT) S.FG[t] = fg_entry(L, S, in, xv, h, k - 1, t);
         SYNC();
         RPROF(14)
         if (red_or(bad)) return 1;         // wrong-sign pivot: the attempt is over, no need to finish the sweep
@@ -1199,14 +1205,20 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         double* p = smem;
         auto take = [&](int cnt) { double* q = p; p += (cnt + 1) & ~1; return q; };
         const int nmax = A.n_max, Rmax = A.R_max, np = L.npair, N1 = L.N + 1;
-        S.x = take(nmax); S.xt = take(nmax); S.dx = take(nmax); S.gf = take(nmax); S.bx = take(nmax);
-        S.y = take(Rmax); S.Einv = take(Rmax); S.yhat = take(Rmax); S.gh = take(Rmax); S.tmp = take(Rmax); S.Lb = take(Rmax); S.Ub = take(Rmax); S.dy = take(3 * N1 + 3);
+        S.x = take(nmax); S.dx = take(nmax); S.gf = take(nmax); S.bx = take(nmax);
+        S.y = take(Rmax); S.Einv = take(Rmax); S.yhat = take(Rmax); S.gh = take(Rmax); S.Lb = take(Rmax); S.Ub = take(Rmax); S.dy = take(3 * N1 + 3);
         S.ct = take(N1); S.st = take(N1); S.cc = take(2 * np); S.ctt = take(N1); S.stt = take(N1); S.cct = take(2 * np);
         S.nu = take(2 * np); S.dnu = take(2 * np); S.crot = take(2 * np);
         S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
-        S.Lall = take(64 * N1); S.lall = take(8 * N1); S.Y = take(MW * 4 * np);
+        S.Lall = take(64 * N1); S.lall = take(8 * N1);
+        {   // the trial point xt and the row staging array tmp are only alive while Y (local solutions, from the local
+            // blocks to the recovery of the step) is dead, and vice versa: they share its storage
+            const int nx = (nmax + 1) & ~1, nr = (Rmax + 1) & ~1, ny = MW * 4 * np;
+            S.Y = take(ny > nx + nr ? ny : nx + nr);
+            S.xt = S.Y; S.tmp = S.Y + nx;
+        }
         S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
-        S.FG = take(48 * N1); S.Mall = take(64); S.mall = take(8);
+        S.FG = take(48); S.Mall = take(64); S.mall = take(8);
         S.offm = reinterpret_cast<int*>(take(8));
         S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
     }
@@ -1569,8 +1581,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
             const bool finite = isfinite(phi_t) && isfinite(th_t);
 #if OBCA_NT == 64
             const bool blocked = (th_t >= theta_max) || (__any(f_valid && th_t >= f_th && phi_t >= f_phi) != 0);
-#else               // the 64 filter entries live in the first wavefront
-            const bool blocked = (th_t >= theta_max) || red_or(lane < 64 && f_valid && th_t >= f_th && phi_t >= f_phi);
+#else               // one filter entry per thread (NT entries)
+            const bool blocked = (th_t >= theta_max) || red_or(f_valid && th_t >= f_th && phi_t >= f_phi);
 #endif
             if (finite && !blocked) {
                 const bool switching = dphi < 0.0 && alpha * pw_dphi > OBCA_DELTA * pw_th;
@@ -1596,14 +1608,13 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
             const int slot = __ffsll((long long)freem) - 1;
             if (lane == slot) { f_valid = true; f_th = tn; f_phi = pn; }
 #else
-            int full = 0;
-            if (lane < 64) {                                                    // whole first wavefront, uniform branch
-                if (f_valid && f_th >= tn && f_phi >= pn) f_valid = false;
-                const unsigned long long freem = __ballot(!f_valid);
-                if (freem == 0ull) full = 1;
-                else if (lane == __ffsll((long long)freem) - 1) { f_valid = true; f_th = tn; f_phi = pn; }
-            }
-            if (red_or(full)) { status = OBCA_STATUS_NUMERIC; break; }
+            if (f_valid && f_th >= tn && f_phi >= pn) f_valid = false;          // dominated entries leave
+            const unsigned long long freem = __ballot(!f_valid);                // per wavefront
+            const double cand = freem ? (double)((lane & ~63) + __ffsll((long long)freem) - 1) : 1e9;
+            const double slot = red_min(cand);                                  // first free entry of the block
+            const int full = slot > 1e8 ? 1 : 0;
+            if (!full && lane == (int)slot) { f_valid = true; f_th = tn; f_phi = pn; }
+            if (full) { status = OBCA_STATUS_NUMERIC; break; }
 #endif
         }
         // ---- accept ------------------------------------------------------------------------------------------
@@ -1743,6 +1754,7 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* __restrict__ Dp, const ObcaLaun
 }
 
 #else
-// four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows)
+// four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
 extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A) { obca_ipm_body<3>(A, blockIdx.x); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A) { obca_ipm_body<5>(A, blockIdx.x); }
 #endif
