@@ -1,7 +1,8 @@
 """Config C3: long horizon, five obstacles (two moving, time-varying rows), lidar-gated mix of
-free-time and fixed-time solves.  These shapes exceed one CU's LDS, so the C ABI routes them to the
-lane-per-instance kernel; parity against the C oracle where the dense oracle finishes in seconds, and
-size-independent properties at N = 20."""
+free-time and fixed-time solves.  These shapes have more rows than one wavefront's registers hold; the C ABI
+routes them to the four-wavefront LDS kernel (both C3 shapes fit one CU's LDS) and anything larger to the
+lane-per-instance kernel.  Parity against the C oracle where the dense oracle finishes in seconds,
+size-independent properties at N = 20, and the three kernels against each other."""
 import os
 
 import numpy as np
@@ -44,6 +45,41 @@ def test_lane_kernel_equals_wave_kernel_where_both_run():
     assert same.mean() > 0.9
     assert np.abs(w["xopt"] - l["xopt"])[same].max() < 1e-9
     assert np.abs(w["xopt"] - l["xopt"]).max() < 1e-5
+
+
+def test_multiwave_kernel_equals_wave_kernel_where_both_run():
+    """four wavefronts per instance run the same code over 256 threads: same iterates as one wavefront"""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    for b, N in ((sc.make_batch(128, 5), 5), (sc.make_batch_c3(32, 5, gated=True), 5)):
+        w, m = run(b, N, "wave"), run(b, N, "multiwave")
+        assert np.array_equal(w["status"], m["status"])
+        same = w["iters"] == m["iters"]
+        assert same.mean() > 0.95
+        assert np.abs(w["xopt"] - m["xopt"])[same].max() < 1e-9
+        assert np.array_equal(run(b, N, "multiwave")["xopt"], m["xopt"])             # deterministic
+
+
+def test_c3_shapes_run_on_the_lds_kernel_and_agree_with_the_lane_kernel():
+    """N = 20: 694 rows (free-time part) and 1114 rows (gated part, 158.7 KB of LDS) -- auto mode must pick the
+    four-wavefront kernel, and its answers must be the lane kernel's"""
+    import ctypes
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import _lib, scenarios as sc
+    lib = _lib.load()
+    for gated in (False, True):
+        b = sc.make_batch_c3(48, 20, gated=gated)
+        d = _lib.ObcaDims()
+        d.N, d.n_obs, d.max_batch = 20, len(b["m"]), 48
+        for i, v in enumerate(b["m"]):
+            d.m[i] = v
+        assert lib.obca_lds_bytes(ctypes.byref(d)) + 64 <= 160 * 1024
+        a, m, l = run(b, 20), run(b, 20, "multiwave"), run(b, 20, "lane")
+        assert np.array_equal(a["xopt"], m["xopt"]) and np.array_equal(a["iters"], m["iters"])      # auto == multiwave
+        both = np.isin(m["status"], (0, 1)) & np.isin(l["status"], (0, 1))
+        assert both.mean() > (0.7 if gated else 0.9)
+        same = both & (m["iters"] == l["iters"])
+        assert same.sum() >= 0.8 * both.sum()
+        assert np.abs(m["xopt"] - l["xopt"])[same].max() < 1e-8
+        assert np.abs(m["xopt"] - l["xopt"])[both].max() < 1e-5
 
 
 def test_c3_free_time_N20_matches_oracle():
