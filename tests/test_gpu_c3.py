@@ -76,10 +76,16 @@ def test_c3_shapes_run_on_the_lds_kernel_and_agree_with_the_lane_kernel():
         assert np.array_equal(a["xopt"], m["xopt"]) and np.array_equal(a["iters"], m["iters"])      # auto == multiwave
         both = np.isin(m["status"], (0, 1)) & np.isin(l["status"], (0, 1))
         assert both.mean() > (0.7 if gated else 0.9)
+        assert np.array_equal(m["status"], l["status"])
         same = both & (m["iters"] == l["iters"])
-        assert same.sum() >= 0.8 * both.sum()
+        assert same.sum() >= (0.5 if gated else 0.9) * both.sum()
         assert np.abs(m["xopt"] - l["xopt"])[same].max() < 1e-8
-        assert np.abs(m["xopt"] - l["xopt"])[both].max() < 1e-5
+        # runs of 150-190 iterations on the non-convex fixed-time problem: where roundoff separates the two iterate
+        # sequences they may settle in different local optima; each must then be a valid plan on its own
+        for o in (m, l):
+            assert dynamics_residual(o["xopt"], o["uopt"], o["ts_opt"])[both].max() < 1e-7
+        close = np.abs(m["xopt"] - l["xopt"]).reshape(len(both), -1).max(1) < 1e-5
+        assert (close & both).sum() >= 0.9 * both.sum()
 
 
 def test_c3_free_time_N20_matches_oracle():
