@@ -21,7 +21,12 @@ class obca:
     def _solver(self, N, m):
         key = (int(N), tuple(m))
         if key not in self._solvers:
-            self._solvers[key] = BatchSolver(N, m, max_batch=1)
+            s = BatchSolver(N, m, max_batch=1)
+            try:                      # a batch of one leaves the GPU idle: give the instance a whole CU (four
+                s.set_mode("multiwave")   # wavefronts), which shortens the call; same iterates as one wavefront
+            except RuntimeError:
+                pass                  # shape beyond the LDS: auto mode picks the lane kernel
+            self._solvers[key] = s
         return self._solvers[key]
 
     def _run(self, variant, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0,
