@@ -94,6 +94,35 @@ def cpu_structured(batch, N):
             "sample": "%d instances of the same batch, structured core on the host, %d OpenMP threads, %.1f s" % (n, cores, dt)}
 
 
+def config_c3(B, N=20, unique=256):
+    """Config C3: N=20, walls + box + two moving boxes, lidar-gated: the free-time sub-batch (obca_mpc4, three
+    static obstacles) and the gated sub-batch (obca_mpc6, five obstacles, time-varying rows), B instances each (the
+    generator's first `unique` instances of each kind, repeated); both run on the four-wavefront LDS kernel."""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+    res = {"workload": "C3 (SURVEY 8d): N=%d, B=%d per sub-batch, %d unique instances each" % (N, B, unique)}
+    for name, gated in (("free_time_obca_mpc4", False), ("gated_obca_mpc6", True)):
+        base = sc.make_batch_c3(unique, N, gated=gated)
+        rep = (B + unique - 1) // unique
+        b = {k: (np.concatenate([v] * rep)[:B] if isinstance(v, np.ndarray) else v) for k, v in base.items()}
+        s = BatchSolver(N, b["m"], B)
+        dv = {k: torch.as_tensor(b[k], device="cuda") for k in ("variant", "x0", "u0", "xref", "A", "b", "Ts", "term")}
+        out = None
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = s.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], SolverParams(), out=out)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        ok = int(((out.status == 0) | (out.status == 1)).sum())
+        res[name] = {"value": ok / best, "unit": "converged solves/s", "ms_per_launch": best * 1e3, "success_rate": ok / B,
+                     "mean_ipm_iters": float(out.iters.float().mean()), "lds_bytes": s.lds_bytes}
+        s.close()
+    return res
+
+
 def closed_loop_c5(B, n_dyn=2, warm_start=None):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds resident in HBM before the clock starts."""
@@ -257,6 +286,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
             line["cpu_structured_core"] = cpu_structured(batch, N)
         if world == 1 and args.closed_loop_rollouts > 0:
+            line["config_c3"] = config_c3(B)
             line["closed_loop"] = closed_loop_c5(args.closed_loop_rollouts)
             # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes
             line["closed_loop_static"] = closed_loop_c5(B, n_dyn=0)
