@@ -55,7 +55,9 @@ typedef struct obca_params {
     double dmin;                       /* clearance (closed_loop.py:64)                           */
     /* interior-point options; <= 0 selects the default in brackets */
     double tol;                        /* [1e-8]  IPOPT tol                                        */
-    double rho;                        /* [1e4]   elastic (l1) penalty, unscaled objective units   */
+    double rho;                        /* [1e4]   elastic (l1) penalty, unscaled objective units; a free-time solve
+                                                   that ends with elastic variables left is repeated once with
+                                                   rho x 100 (exact-penalty escalation)                      */
     double feas_tol;                   /* [1e-6]  largest elastic variable still called feasible   */
     int32_t max_iter_free;             /* [3000]  IPOPT default, variant 4                         */
     int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8                       */

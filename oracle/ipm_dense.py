@@ -117,7 +117,27 @@ def split_rows(p):
     return hard, term
 
 
+RHO_ESCALATION = 100.0
+
+
 def solve(p, opts=None, trace=None):
+    """The elastic IPM with ONE penalty escalation for the free-time problem: the l1 penalty is exact only while rho
+    exceeds the multipliers; if obca_mpc4 converges with elastic variables left (which is what "infeasible" looks
+    like, but also what a too small rho looks like -- seen on the open-loop problem of demo1, N = 10) the solve is
+    repeated from the cold start with rho * 100.  A genuinely infeasible problem stays infeasible.  The fixed-time
+    variants are not escalated: the reference has its own obca_mpc6 -> obca_mpc8 fallback for them."""
+    r = _solve_once(p, opts, trace)
+    if r.status == STATUS_INFEASIBLE and p.variant == 4 and not (opts or {}).get("no_escalation"):
+        o2 = dict(opts or {})
+        o2["rho"] = (opts or {}).get("rho", DEFAULTS["rho"]) * RHO_ESCALATION
+        r2 = _solve_once(p, o2, trace)
+        r2.iters += r.iters
+        r2.nfact = getattr(r2, "nfact", 0) + getattr(r, "nfact", 0)
+        return r2
+    return r
+
+
+def _solve_once(p, opts=None, trace=None):
     o = options_for(p.variant)
     if opts:
         o.update(opts)

@@ -722,6 +722,16 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         o.tol = prm->tol > 0 ? prm->tol : 1e-8; o.rho = prm->rho > 0 ? prm->rho : 1e4; o.feas_tol = prm->feas_tol > 0 ? prm->feas_tol : 1e-6;
         o.max_iter_free = prm->max_iter_free > 0 ? prm->max_iter_free : 3000; o.max_iter_fixed = prm->max_iter_fixed > 0 ? prm->max_iter_fixed : 1000;
         status[q] = solve_one(&p, &o, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL);
+        if (status[q] == ST_INFEASIBLE && p.variant == 4) {
+            /* one penalty escalation for the free-time problem (see oracle/ipm_dense.py:solve): cold start again, rho x 100 */
+            Opts o2 = o;
+            o2.rho = o.rho * 100.0;
+            const int it1 = iters[q];
+            const double nf1 = info ? info[(size_t)q * 4 + 3] : 0.0;
+            status[q] = solve_one(&p, &o2, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL);
+            iters[q] += it1;
+            if (info) info[(size_t)q * 4 + 3] += nf1;
+        }
         free(Arep); free(brep);
     }
     return 0;

@@ -59,3 +59,20 @@ def test_batched_rollouts_equal_single_rollouts():
         assert a.k == b.k
         np.testing.assert_array_equal(np.asarray(a.x_closed), np.asarray(b.x_closed))   # same kernel, same inputs
         assert a.T_closed == b.T_closed
+
+
+def test_open_loop_free_time_planner_demo1():
+    """reference `mpc_openLoop_freeTime` (src/closed_loop.py:113-120) at the recommended N_free = 10: needs the penalty
+    escalation (rho 1e4 -> 1e6); the plan goes round the box and ends at the goal"""
+    import numpy as np
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
+    cl = closedLoop(problemSetting("demo1"))
+    cl.N_free = 10
+    cl.mpc_openLoop_freeTime()
+    assert cl.feas == True  # noqa: E712
+    assert cl.xOpt[1].max() > 5.5 and abs(cl.xOpt[0, -1] - 38.0) < 1e-6 and abs(cl.xOpt[1, -1] - 4.0) < 1e-6
+    h = cl.Ts_opt
+    x, u = cl.xOpt, cl.uOpt
+    nxt = x[:, :-1] + h * np.stack([u[0] * np.cos(x[2, :-1]), u[0] * np.sin(x[2, :-1]), u[1]])
+    assert np.max(np.abs(nxt - x[:, 1:])) < 1e-7

@@ -60,3 +60,27 @@ def test_long_horizon_window_converges():
     h = ts
     nxt = x[:, :-1] + h * np.stack([u[0] * np.cos(x[2, :-1]), u[0] * np.sin(x[2, :-1]), u[1]])
     assert np.max(np.abs(nxt - x[:, 1:])) < 1e-7 and np.max(np.abs(x[:, -1] - cl.xref[:, -1])) < 1e-7
+
+
+def test_penalty_escalation_solves_the_open_loop_problem():
+    """demo1, N = 10, the reference's open-loop free-time problem (`startGoal_only` reference, src/closed_loop.py:113-120):
+    with rho = 1e4 alone the solve ends at an infeasible stationary point (the straight line that jumps over the box);
+    the one escalation to rho = 1e6 finds the feasible plan.  Structured core and dense C oracle agree."""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import pack_reference_call
+    s = native_build.LpiObca()
+    cl = closedLoop(problemSetting("demo1"), solver=s)
+    cl.N_free = 10
+    cl.mpc_openLoop_freeTime()
+    assert cl.feas and s.calls[-1]["status"] == 0
+    x = cl.xOpt
+    assert x[1].max() > 5.5 and abs(x[0, -1] - 38.0) < 1e-6                    # goes round the box, reaches the goal
+    c = s.calls[-1]
+    ref = c_oracle.solve_batch(4, 10, c["m"], c["x0"][None], c["u0"][None], c["xref"][None], c["A"][None], c["b"][None],
+                               [c["Ts"]], None, threads=1)
+    assert ref["status"][0] == 0                     # ~340 iterations over the two passes; the paths differ by roundoff
+    assert np.max(np.abs(ref["xopt"][0] - x)) < 1e-5 and abs(ref["ts_opt"][0] - cl.Ts_opt) < 1e-6
+    no_esc = native_build.lpi_solve(4, 10, c["m"], c["x0"][None], c["u0"][None], c["xref"][None], c["A"][None], c["b"][None],
+                                    [c["Ts"]], None, c_oracle.default_params(rho=1e6))
+    assert no_esc["status"][0] == 0 and no_esc["iters"][0] < c["iters"]         # the escalated pass alone

@@ -38,6 +38,7 @@
 #define OBCA_KAPPA_W_MINUS (1.0 / 3.0)
 #define OBCA_MAX_GRADIENT 100.0
 #define OBCA_ACCEPTABLE_ITER 15
+#define OBCA_RHO_ESCALATION 100.0   /* obca_mpc4 only: one retry with rho x 100 when elastic variables remain */
 
 #define OBCA_INST_DOUBLES 64   /* LDS reserved for the per-instance constant block (struct Inst) */
 
@@ -62,6 +63,8 @@ struct ObcaLaunch {
     double* warm_z;        /* [B,n_max] primal vector of the last successful solve (in/out) or NULL: obca_set_warm_start */
     const int32_t* warm_use; /* [B] != 0: start from warm_z shifted by one stage; NULL = every instance          */
     double warm_mu;        /* barrier parameter a warm-started solve begins with                                 */
+    int32_t escalation_pass; /* 1: second pass with rho x 100 -- only instances that the first pass left "infeasible" on
+                                the free-time problem are solved again, the others return at once; counts accumulate */
     ObcaParamsDev prm;
 };
 

@@ -1178,6 +1178,12 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         if (lane == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; }
         return;
     }
+    // Penalty escalation (one, free-time problem only): the l1 penalty is exact only while rho exceeds the multipliers.
+    // If obca_mpc4 converges with elastic variables left -- what "infeasible" looks like, but also what a too small rho
+    // looks like (the open-loop problem of demo1 at N = 10) -- the caller runs a second pass with rho x 100 in which
+    // every other instance returns here (same rule in oracle/ipm_dense.py:solve).  A genuinely infeasible problem stays
+    // infeasible; the fixed-time variants are not escalated, the reference has its obca_mpc6 -> obca_mpc8 fallback.
+    if (A.escalation_pass && !(A.variant[inst] == 4 && A.status[inst] == OBCA_STATUS_INFEASIBLE)) return;
 
     // ---- layout ------------------------------------------------------------------------------------
     Lay L;
@@ -1692,10 +1698,10 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         if (lane == 0) {
             A.ts_opt[inst] = L.free_T ? S.x[L.iT()] * in.Ts : in.Ts;
             A.status[inst] = status;
-            A.iters[inst] = it;
+            A.iters[inst] = it + (A.escalation_pass ? A.iters[inst] : 0);
             if (A.info) {
                 double* io = A.info + (size_t)inst * 4;
-                io[0] = f / sf; io[1] = elastic_max; io[2] = E0; io[3] = (double)nfact;
+                io[0] = f / sf; io[1] = elastic_max; io[2] = E0; io[3] = (double)nfact + (A.escalation_pass ? io[3] : 0.0);
             }
         }
     }
@@ -1725,13 +1731,19 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
         if (D.flags[b] != OBCA_RUN) break;
         const int g = D.sel[b];
         for (int attempt = 0; attempt < 2; ++attempt) {
+            // second attempt: obca_mpc4 -> the escalated pass (rho x 100; returns at once unless the first pass ended
+            // "infeasible"); obca_mpc6 -> obca_mpc8 where obca_mpc6 failed.  One call site: the body is inlined once.
+            const ObcaLaunch* Lp = launches + g;
             if (attempt == 1) {
-                if (g == 0) break;
-                if (lane == 0) rollout::make_retry(D, g, b);
-                __syncthreads();
-                if (D.var8[g][b] != 8) break;
+                if (g == 0) Lp = launches + 2 * rollout::MAX_GROUPS;
+                else {
+                    if (lane == 0) rollout::make_retry(D, g, b);
+                    __syncthreads();
+                    if (D.var8[g][b] != 8) break;
+                    Lp = launches + g + rollout::MAX_GROUPS;
+                }
             }
-            obca_ipm_body<RPL>(launches[g + attempt * rollout::MAX_GROUPS], b);
+            obca_ipm_body<RPL>(*Lp, b);
             __syncthreads();
         }
         if (lane == 0) rollout::finish(D, b);
