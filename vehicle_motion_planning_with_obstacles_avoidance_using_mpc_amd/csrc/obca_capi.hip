@@ -225,19 +225,16 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw || !lane) {
-        // two passes: the second one (rho x 100) only re-solves free-time instances the first left "infeasible"
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1) { L.prm.opt.rho *= OBCA_RHO_ESCALATION; L.escalation_pass = 1; }
-            if (mw)
-                hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
-                                   (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
-            else if (h->R_max <= 256)
-                hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
-            else if (h->R_max <= 320)
-                hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
-            else
-                hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
-        }
+        // (the kernels run the escalated second solve of a free-time instance themselves)
+        if (mw)
+            hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
+                               (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+        else if (h->R_max <= 256)
+            hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+        else if (h->R_max <= 320)
+            hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+        else
+            hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
     } else {
         if (!h->ws || !h->d_offm) {
             if (!h->ws && hipMalloc(&h->ws, sizeof(double) * (size_t)h->ws_doubles * h->ws_stride) != hipSuccess) { h->ws = nullptr; return OBCA_E_NOMEM; }

@@ -63,8 +63,6 @@ struct ObcaLaunch {
     double* warm_z;        /* [B,n_max] primal vector of the last successful solve (in/out) or NULL: obca_set_warm_start */
     const int32_t* warm_use; /* [B] != 0: start from warm_z shifted by one stage; NULL = every instance          */
     double warm_mu;        /* barrier parameter a warm-started solve begins with                                 */
-    int32_t escalation_pass; /* 1: second pass with rho x 100 -- only instances that the first pass left "infeasible" on
-                                the free-time problem are solved again, the others return at once; counts accumulate */
     ObcaParamsDev prm;
 };
 

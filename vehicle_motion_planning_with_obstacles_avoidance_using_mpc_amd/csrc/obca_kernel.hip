@@ -1170,7 +1170,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
 
 // ================================================================== the kernel
 template <int RPL>
-__device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int inst) {
+__device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int inst, const int pass) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     if (inst >= A.B) return;
@@ -1180,10 +1180,10 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     }
     // Penalty escalation (one, free-time problem only): the l1 penalty is exact only while rho exceeds the multipliers.
     // If obca_mpc4 converges with elastic variables left -- what "infeasible" looks like, but also what a too small rho
-    // looks like (the open-loop problem of demo1 at N = 10) -- the caller runs a second pass with rho x 100 in which
-    // every other instance returns here (same rule in oracle/ipm_dense.py:solve).  A genuinely infeasible problem stays
+    // looks like (the open-loop problem of demo1 at N = 10) -- the caller runs the body a second time (pass = 1) with
+    // rho x 100; every other instance returns here (same rule in oracle/ipm_dense.py:solve).  A genuinely infeasible problem stays
     // infeasible; the fixed-time variants are not escalated, the reference has its obca_mpc6 -> obca_mpc8 fallback.
-    if (A.escalation_pass && !(A.variant[inst] == 4 && A.status[inst] == OBCA_STATUS_INFEASIBLE)) return;
+    if (pass && !(A.variant[inst] == 4 && A.status[inst] == OBCA_STATUS_INFEASIBLE)) return;
 
     // ---- layout ------------------------------------------------------------------------------------
     Lay L;
@@ -1267,7 +1267,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     }
     SYNC();
 
-    const ObcaOptsDev O = A.prm.opt;          // by value: A may live in HBM (fused closed-loop kernel)
+    ObcaOptsDev O = A.prm.opt;                // by value: A may live in HBM (fused closed-loop kernel)
+    if (pass) O.rho *= OBCA_RHO_ESCALATION;
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
@@ -1698,20 +1699,31 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         if (lane == 0) {
             A.ts_opt[inst] = L.free_T ? S.x[L.iT()] * in.Ts : in.Ts;
             A.status[inst] = status;
-            A.iters[inst] = it + (A.escalation_pass ? A.iters[inst] : 0);
+            A.iters[inst] = it + (pass ? A.iters[inst] : 0);
             if (A.info) {
                 double* io = A.info + (size_t)inst * 4;
-                io[0] = f / sf; io[1] = elastic_max; io[2] = E0; io[3] = (double)nfact + (A.escalation_pass ? io[3] : 0.0);
+                io[0] = f / sf; io[1] = elastic_max; io[2] = E0; io[3] = (double)nfact + (pass ? io[3] : 0.0);
             }
         }
     }
 }
 
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
+// the solve and, for a free-time instance that ended "infeasible", the escalated solve.  Two straight-line call sites
+// (a loop around one call site cost 160 B of scratch per lane in the hot copy); the second copy is cold code.
+template <int RPL>
+__device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A) {
+    const int inst = blockIdx.x;
+    obca_ipm_body<RPL>(A, inst, 0);
+    if (inst >= A.B) return;
+    __syncthreads();                                            // status written by thread 0 of this workgroup
+    if (A.variant[inst] == 4 && A.status[inst] == OBCA_STATUS_INFEASIBLE) obca_ipm_body<RPL>(A, inst, 1);
+}
+
 #if OBCA_NT == 64
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A) { obca_ipm_body<4>(A, blockIdx.x); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A) { obca_ipm_body<5>(A, blockIdx.x); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A) { obca_ipm_body<6>(A, blockIdx.x); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A) { solve_with_escalation<4>(A); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A) { solve_with_escalation<5>(A); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A) { solve_with_escalation<6>(A); }
 
 // ================================================================== fused closed loop
 // One wavefront owns one rollout for its whole life: lane 0 runs the harness of csrc/obca_rollout_core.h between
@@ -1735,15 +1747,14 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
             // "infeasible"); obca_mpc6 -> obca_mpc8 where obca_mpc6 failed.  One call site: the body is inlined once.
             const ObcaLaunch* Lp = launches + g;
             if (attempt == 1) {
-                if (g == 0) Lp = launches + 2 * rollout::MAX_GROUPS;
-                else {
+                if (g != 0) {
                     if (lane == 0) rollout::make_retry(D, g, b);
                     __syncthreads();
                     if (D.var8[g][b] != 8) break;
                     Lp = launches + g + rollout::MAX_GROUPS;
                 }
             }
-            obca_ipm_body<RPL>(*Lp, b);
+            obca_ipm_body<RPL>(*Lp, b, (attempt == 1 && g == 0) ? 1 : 0);
             __syncthreads();
         }
         if (lane == 0) rollout::finish(D, b);
@@ -1767,6 +1778,6 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* __restrict__ Dp, const ObcaLaun
 
 #else
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A) { obca_ipm_body<3>(A, blockIdx.x); }
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A) { obca_ipm_body<5>(A, blockIdx.x); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A) { solve_with_escalation<3>(A); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A) { solve_with_escalation<5>(A); }
 #endif
