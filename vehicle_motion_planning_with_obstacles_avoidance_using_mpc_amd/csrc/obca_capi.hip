@@ -9,11 +9,11 @@
 #include "obca_device.h"
 #include "obca_lpi_core.h"
 
-extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A);
-extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A);
-extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A);
-extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A);          // four wavefronts per instance (obca_kernel_mw.hip)
-extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A);
+extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2);
+extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2);
+extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2);
+extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2);          // four wavefronts per instance (obca_kernel_mw.hip)
+extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2);
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
 struct obca_handle {
@@ -225,16 +225,18 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw || !lane) {
-        // (the kernels run the escalated second solve of a free-time instance themselves)
+        // the kernels run the escalated second solve of a free-time instance themselves, from their own descriptor
+        ObcaLaunch L2 = L;
+        L2.prm.opt.rho *= OBCA_RHO_ESCALATION;
         if (mw)
             hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
-                               (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+                               (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
         else if (h->R_max <= 256)
-            hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+            hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
         else if (h->R_max <= 320)
-            hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+            hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
         else
-            hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L);
+            hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
     } else {
         if (!h->ws || !h->d_offm) {
             if (!h->ws && hipMalloc(&h->ws, sizeof(double) * (size_t)h->ws_doubles * h->ws_stride) != hipSuccess) { h->ws = nullptr; return OBCA_E_NOMEM; }

@@ -1267,8 +1267,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     }
     SYNC();
 
-    ObcaOptsDev O = A.prm.opt;                // by value: A may live in HBM (fused closed-loop kernel)
-    if (pass) O.rho *= OBCA_RHO_ESCALATION;
+    const ObcaOptsDev O = A.prm.opt;          // by value: A may live in HBM (fused closed-loop kernel); the descriptor of
+                                              // an escalated pass carries rho x 100 itself
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
@@ -1709,21 +1709,23 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
 }
 
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
-// the solve and, for a free-time instance that ended "infeasible", the escalated solve.  Two straight-line call sites
-// (a loop around one call site cost 160 B of scratch per lane in the hot copy); the second copy is cold code.
+// The solve and, for a free-time instance that ended "infeasible", the escalated solve: two inlined copies of the
+// body, the second one cold.  The second copy reads its OWN descriptor (A2 = A with rho x 100, a second kernel
+// argument): were both copies to read A, the compiler would merge their identical prologue expressions and keep those
+// values alive across the whole first solve, which showed up as scratch traffic in the hot copy.
 template <int RPL>
-__device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A) {
+__device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const ObcaLaunch& A2) {
     const int inst = blockIdx.x;
     obca_ipm_body<RPL>(A, inst, 0);
     if (inst >= A.B) return;
     __syncthreads();                                            // status written by thread 0 of this workgroup
-    if (A.variant[inst] == 4 && A.status[inst] == OBCA_STATUS_INFEASIBLE) obca_ipm_body<RPL>(A, inst, 1);
+    if (A2.variant[inst] == 4 && A2.status[inst] == OBCA_STATUS_INFEASIBLE) obca_ipm_body<RPL>(A2, inst, 1);
 }
 
 #if OBCA_NT == 64
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A) { solve_with_escalation<4>(A); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A) { solve_with_escalation<5>(A); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A) { solve_with_escalation<6>(A); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<4>(A, A2); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<5>(A, A2); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<6>(A, A2); }
 
 // ================================================================== fused closed loop
 // One wavefront owns one rollout for its whole life: lane 0 runs the harness of csrc/obca_rollout_core.h between
@@ -1747,7 +1749,8 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
             // "infeasible"); obca_mpc6 -> obca_mpc8 where obca_mpc6 failed.  One call site: the body is inlined once.
             const ObcaLaunch* Lp = launches + g;
             if (attempt == 1) {
-                if (g != 0) {
+                if (g == 0) Lp = launches + 2 * rollout::MAX_GROUPS;
+                else {
                     if (lane == 0) rollout::make_retry(D, g, b);
                     __syncthreads();
                     if (D.var8[g][b] != 8) break;
@@ -1778,6 +1781,6 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* __restrict__ Dp, const ObcaLaun
 
 #else
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A) { solve_with_escalation<3>(A); }
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A) { solve_with_escalation<5>(A); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<5>(A, A2); }
 #endif

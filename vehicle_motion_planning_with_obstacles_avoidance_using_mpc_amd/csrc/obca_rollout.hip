@@ -46,7 +46,7 @@ struct obca_rollouts {
     // fused path: descriptors in HBM for the persistent one-wave-per-rollout kernel (obca_kernel.hip)
     rollout::Dev* dD;
     ObcaLaunch* dL;
-    ObcaLaunch hL[2 * rollout::MAX_GROUPS];
+    ObcaLaunch hL[2 * rollout::MAX_GROUPS + 1];        // [2*MAX_GROUPS] = escalated pass of group 0 (obca_mpc4): rho x 100
     bool fused_ok;
     int32_t rows_max;
     int64_t lds_max;
@@ -135,7 +135,7 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     }
     if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
     r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0; r->warm_mu = 0.0;
-    if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS))) rc = OBCA_E_NOMEM;
+    if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS + 1))) rc = OBCA_E_NOMEM;
     if (rc != OBCA_OK) { obca_rollouts_destroy(r); return rc; }
     *out = r;
     return OBCA_OK;
@@ -196,6 +196,8 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
             if (g > 0) r->hL[g + a * rollout::MAX_GROUPS].R_max -= 3;
             if (r->hL[g + a * rollout::MAX_GROUPS].R_max > r->rows_max) r->rows_max = r->hL[g + a * rollout::MAX_GROUPS].R_max;
         }
+    r->hL[2 * rollout::MAX_GROUPS] = r->hL[0];
+    r->hL[2 * rollout::MAX_GROUPS].prm.opt.rho *= OBCA_RHO_ESCALATION;
     if (hipMemcpyAsync(r->dD, &r->D, sizeof(rollout::Dev), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(r->dL, r->hL, sizeof(r->hL), hipMemcpyHostToDevice, s) != hipSuccess)
         return OBCA_E_HIP;
