@@ -272,8 +272,8 @@ def main():
             "attempted_steps_per_s": total * args.steps / elapsed, "success_rate": n_ok / total, "mean_ipm_iters": it_sum / total, "mean_kkt_factorisations": nf_sum / total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         # HBM bytes per launch from the PMC passes committed under profiles/ (r01h: FETCH_SIZE x2 + WRITE_SIZE)
-                         "traffic": 14.09e6 if (B, N, M) == (8192, 5, 6) else None,
+                         # HBM bytes per launch from the PMC passes committed under profiles/ (r01i: FETCH_SIZE x2 + WRITE_SIZE)
+                         "traffic": 14.8e6 if (B, N, M) == (8192, 5, 6) else None,
                          "kernel": "obca_ipm_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_instance": ab,
                          "fp64_model_frac": value / world * (nf_sum / total) * (N + 1) * (32 ** 3 / 3 + 2 * 32 ** 2) / 78.6e12
                          if M == 6 else None,
