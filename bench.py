@@ -284,14 +284,23 @@ def main():
             line["batch_1024"] = small
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
-            line["cpu_structured_core"] = cpu_structured(batch, N)
+            try:
+                line["cpu_structured_core"] = cpu_structured(batch, N)
+            except Exception as e:              # noqa: BLE001  (context figure only)
+                line["cpu_structured_core"] = {"value": None, "error": repr(e)}
         if world == 1 and args.closed_loop_rollouts > 0:
-            line["config_c3"] = config_c3(B)
-            line["closed_loop"] = closed_loop_c5(args.closed_loop_rollouts)
-            # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes
-            line["closed_loop_static"] = closed_loop_c5(B, n_dyn=0)
-            # optional extension, NOT reference behaviour (the reference cold-starts every solve): shifted previous plan
-            line["closed_loop_static_warm_start"] = closed_loop_c5(B, n_dyn=0, warm_start=0.1)
+            # secondary figures: a failure in one of them must not cost the headline line
+            extras = (("config_c3", lambda: config_c3(B)),
+                      ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts)),
+                      # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes
+                      ("closed_loop_static", lambda: closed_loop_c5(B, n_dyn=0)),
+                      # optional extension, NOT reference behaviour (the reference cold-starts): shifted previous plan
+                      ("closed_loop_static_warm_start", lambda: closed_loop_c5(B, n_dyn=0, warm_start=0.1)))
+            for name, fn in extras:
+                try:
+                    line[name] = fn()
+                except Exception as e:          # noqa: BLE001
+                    line[name] = {"error": repr(e)}
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()
