@@ -4,8 +4,10 @@ from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import _lib,
 _lib.LIB_PATH = _lib.LIB_PATH.replace('libobca_mpc.so', 'libobca_mpc_prof.so')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
 B=int(sys.argv[1]) if len(sys.argv)>1 else 768
-b=sc.make_batch_c3(B,5,gated=True) if (len(sys.argv)>2 and sys.argv[2]=='c3') else sc.make_batch(B,5)
-s=BatchSolver(5,b['m'],B)
+N=int(sys.argv[3]) if len(sys.argv)>3 else 5
+kind=sys.argv[2] if len(sys.argv)>2 else 'c2'
+b=sc.make_batch_c3(B,N,gated=True) if kind=='c3' else sc.make_batch_c3(B,N,gated=False) if kind=='c3free' else sc.make_batch(B,N)
+s=BatchSolver(N,b['m'],B)
 prof=torch.zeros(B,20,dtype=torch.float64,device='cuda')
 s.lib.obca_set_profile_buffer(s._h, ctypes.c_void_p(prof.data_ptr()))
 for _ in range(2):
