@@ -1064,8 +1064,11 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
                 if (a == 0) { S.kapk[2 * k] = k0; S.kapk[2 * k + 1] = k1; }
             }
         }
-        if (k > 0)                          // phase A of this stage is over: its [F G] can make room for the next one
-            for (int t = lane; t < 48; t += NT) S.FG[t] = fg_entry(L, S, in, xv, h, k - 1, t);
+        if (k > 0) {                        // phase A of this stage is over: its [F G] can make room for the next one
+            // (with four wavefronts the second one writes it: it has no entry of P_k to compute)
+            const int t = NT > 64 ? lane - 64 : lane;
+            if (t >= 0 && t < 48) S.FG[t] = fg_entry(L, S, in, xv, h, k - 1, t);
+        }
         SYNC();
         RPROF(14)
         if (red_or(bad)) return 1;         // wrong-sign pivot: the attempt is over, no need to finish the sweep
