@@ -1016,8 +1016,9 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         double E[3], gh[3], X[36], qt[6], Mi[9];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { E[j] = 1.0 / S.Einv[L.r_dyn + 3 * k + j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
-        bad |= soft_min_regs(S.Pk + 36 * (k + 1), S.qk + 6 * (k + 1), E, X, qt, Mi);
-        if (NT == 64 || lane < 64) {
+        if (NT == 64 || lane < 64) {        // (four wavefronts: the serial sweep is the first wavefront's job alone --
+            // the others would only repeat it and compete for the LDS)
+            bad |= soft_min_regs(S.Pk + 36 * (k + 1), S.qk + 6 * (k + 1), E, X, qt, Mi);
             const int a = lane >> 3, b = lane & 7;
             double fa[6], fb[6];
 #pragma unroll
@@ -1045,6 +1046,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         SYNC();
         RPROF(13)
         // ---- phase B ----------------------------------------------------------------------------------
+        if (NT == 64 || lane < 64) {
         const double m00 = S.Mall[8 * 6 + 6], m01 = 0.5 * (S.Mall[8 * 6 + 7] + S.Mall[8 * 7 + 6]), m11 = S.Mall[8 * 7 + 7];
         const double d1 = m11 - m01 * m01 / m00;
         if (!(m00 > 0.0) || !(d1 > 0.0)) bad = 1;
@@ -1064,6 +1066,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
                 if (a == 0) { S.kapk[2 * k] = k0; S.kapk[2 * k + 1] = k1; }
             }
         }
+        }
         if (k > 0) {                        // phase A of this stage is over: its [F G] can make room for the next one
             // (with four wavefronts the second one writes it: it has no entry of P_k to compute)
             const int t = NT > 64 ? lane - 64 : lane;
@@ -1077,12 +1080,15 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     double E0[3], g0[3], X[36], qt[6], Mi0[9];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { E0[j] = 1.0 / S.Einv[L.r_init + j]; g0[j] = S.gh[L.r_init + j]; }
-    bad |= soft_min_regs(S.Pk, S.qk, E0, X, qt, Mi0);
-    if (L.free_T && !(X[35] > 0.0)) bad = 1;
+    if (NT == 64 || lane < 64) {
+        bad |= soft_min_regs(S.Pk, S.qk, E0, X, qt, Mi0);
+        if (L.free_T && !(X[35] > 0.0)) bad = 1;
+    }
     bad = red_or(bad);
     RPROF(15)
     if (bad) return 1;
-    // ---- forward pass: every lane carries the (tiny) state redundantly, lane 0 stores
+    // ---- forward pass: every lane (of the first wavefront) carries the (tiny) state redundantly, lane 0 stores
+    if (NT == 64 || lane < 64) {
     double dT = 0.0;
     if (L.free_T) dT = -(qt[5] - (X[30] * g0[0] + X[31] * g0[1] + X[32] * g0[2])) / X[35];
     double dp[3], up[2] = {0.0, 0.0};
@@ -1148,6 +1154,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         }
         dp[0] = dn[0]; dp[1] = dn[1]; dp[2] = dn[2];
         up[0] = u[0]; up[1] = u[1];
+    }
     }
     SYNC();
     RPROF(16)
