@@ -62,6 +62,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libobca_mpc.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(expected at %s). There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime; libobca_mpc.so is linked against the system one.  Whichever is loaded
+    # first serves both -- load torch's first, always, so that device memory handed over by torch and our launches
+    # live in the same runtime (the other order made hipSetDevice fail in obca_create).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32p = ctypes.c_void_p, ctypes.c_void_p
     lib.obca_create.argtypes = [ctypes.POINTER(ObcaDims), ctypes.POINTER(ctypes.c_void_p)]
