@@ -123,6 +123,23 @@ int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t B,
 int64_t obca_primal_size(const obca_dims* dims);
 int obca_set_warm_start(obca_handle* h, double* z, const int32_t* use, double mu_init);
 
+/* Optional certificate output -- NOT part of the reference's call surface (its callers only read sol.value(x), sol.value(u),
+ * src/obca.py:1057-1059), for KKT certificates of the ORIGINAL NLP at the returned point.  While set, every solve stores
+ *   z [max_batch, obca_primal_size(dims)]  its final primal vector: per stage k the pose (3), the input (2, k < N),
+ *                                          lambda_k (M) and mu_k (4 n_obs); the time scale Topt last (variant 4)
+ *   y [max_batch, obca_dual_size(dims)]    the multipliers of the NLP's constraint rows in the objective's own units
+ *                                          (the solver's internal objective scaling undone), sign convention
+ *                                          grad f + sum_r y_r grad g_r = 0, rows in the order
+ *                                            x_0 == x0 (3), dynamics (3N), [x_N == xref_N (3): variant 4],
+ *                                            position box (2(N+1)), input box (2N), acceleration rows (2N),
+ *                                            [Topt > 0, Topt bounds (2; each stands for the N+1 tied copies): variant 4],
+ *                                            [terminal set x, y (2): variant 6], ||A'lambda||^2 <= 1 (per stage and obstacle),
+ *                                            distance rows (per stage and obstacle), lambda >= 0 ((N+1) M), mu >= 0 ((N+1) 4 n_obs),
+ *                                          followed by the rotation equalities (2 per stage and obstacle).
+ * Either pointer may be NULL; both NULL switches it off. */
+int64_t obca_dual_size(const obca_dims* dims);
+int obca_set_certificate_buffers(obca_handle* h, double* z, double* y);
+
 /* Kernel selection: 0 = auto (default; also env OBCA_MODE): one wavefront per instance when its rows fit the
  * wavefront's registers (<= 384 rows) and its working set one CU's LDS; else four wavefronts per instance when the
  * working set still fits the LDS (<= 768 rows, e.g. N = 20 with three obstacles); else the lane-per-instance kernel.

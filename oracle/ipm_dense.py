@@ -13,9 +13,9 @@ form of the NLP -- the same l1 relaxation IPOPT's own restoration phase solves,
 kept on throughout with the true objective:
 
     min f(x) + rho * sum_r (p_r + n_r)
-    s.t. c_h(x) = 0                          hard rows: initial state, dynamics, rotation equalities
-         g_r(x) - s_r - p_r + n_r = 0        elastic rows: every inequality and the terminal equalities
-         L_r <= s_r <= U_r,  p_r, n_r >= 0   (terminal equalities: s_r == 0)
+    s.t. c_h(x) = 0                          hard rows: the rotation equalities G'mu + R'A'lambda = 0 only
+         g_r(x) - s_r - p_r + n_r = 0        elastic rows: every inequality and every other equality
+         L_r <= s_r <= U_r,  p_r, n_r >= 0   (initial state, dynamics, terminal equalities: s_r == 0)
 
 Opti poses every inequality -- simple bounds included -- as a general
 constraint, so all of them are rows here; decision variables are free.  With
@@ -109,7 +109,7 @@ def _ldl_inertia(K):
 
 
 def split_rows(p):
-    """hard equality rows (init, dyn, rot) and elastic rows (terminal equalities + all inequalities)"""
+    """hard equality rows (rot) and elastic equality rows (init, dyn, terminal); the inequalities are all elastic"""
     lay = p.eq_layout()
     kinds = HARD_KINDS
     hard = np.array([i for i, r in enumerate(lay) if r[0] in kinds], dtype=int)
@@ -436,8 +436,9 @@ def _solve_once(p, opts=None, trace=None):
                 accepted = True
                 step = (alpha, dx, ds, dp, dn, dyh, dye)
                 break
-            if first_trial and th_t >= th and ev is not None:
+            if first_trial and th_t >= th and ev is not None and o["max_soc"] > 0:
                 # second-order correction
+                res.soc_tried = getattr(res, "soc_tried", 0) + 1
                 c_soc = alpha * ch + ev[0]
                 g_soc = alpha * r_g + (ev[1] - pt_[1] - pt_[2] + pt_[3])
                 th_old = th_t
@@ -448,6 +449,7 @@ def _solve_once(p, opts=None, trace=None):
                     pts, th_s, phi_s, evs = trial(a_soc, dxs, dss, dps, dns)
                     ok_s, aug_s = acceptable(alpha, th_s, phi_s)
                     if ok_s:
+                        res.soc_accepted = getattr(res, "soc_accepted", 0) + 1
                         accepted = True
                         pt_, th_t, phi_t, ev, aug = pts, th_s, phi_s, evs, aug_s
                         step = (a_soc, dxs, dss, dps, dns, dyhs, dyes)

@@ -19,10 +19,12 @@ extern "C" int lpi_host_solve_batch_warm(int N, int n_obs, const int* m, const i
                                          const double* x0, const double* u0, const double* xref, const double* A,
                                          const double* b, const double* Ts, const double* term, const HostParams* p,
                                          double* xopt, double* uopt, double* ts_opt, int* status, int* iters, double* info,
-                                         double* warm_z, const int* warm_use, double warm_mu) {
+                                         double* warm_z, const int* warm_use, double warm_mu,
+                                         double* cert_z = nullptr, double* cert_y = nullptr) {
     ObcaLaunch L;
     memset(&L, 0, sizeof(L));
     L.warm_z = warm_z; L.warm_use = warm_use; L.warm_mu = warm_mu;
+    L.cert_z = cert_z; L.cert_y = cert_y;
     int offm[OBCA_MAX_OBST + 1];
     int M = 0;
     offm[0] = 0;
@@ -79,4 +81,14 @@ extern "C" int lpi_host_solve_batch(int N, int n_obs, const int* m, const int* v
                                     double* xopt, double* uopt, double* ts_opt, int* status, int* iters, double* info) {
     return lpi_host_solve_batch_warm(N, n_obs, m, variant, B, x0, u0, xref, A, b, Ts, term, p, xopt, uopt, ts_opt, status, iters,
                                      info, nullptr, nullptr, 0.0);
+}
+
+// with the certificate buffers of obca_set_certificate_buffers: cert_z [B, n_max], cert_y [B, R_max + 2 npair]
+extern "C" int lpi_host_solve_batch_cert(int N, int n_obs, const int* m, const int* variant, int B,
+                                         const double* x0, const double* u0, const double* xref, const double* A,
+                                         const double* b, const double* Ts, const double* term, const HostParams* p,
+                                         double* xopt, double* uopt, double* ts_opt, int* status, int* iters, double* info,
+                                         double* cert_z, double* cert_y) {
+    return lpi_host_solve_batch_warm(N, n_obs, m, variant, B, x0, u0, xref, A, b, Ts, term, p, xopt, uopt, ts_opt, status, iters,
+                                     info, nullptr, nullptr, 0.0, cert_z, cert_y);
 }

@@ -27,6 +27,7 @@ def load():
                         SRC, "-o", OUT], check=True)
     _lib = ctypes.CDLL(OUT)
     _lib.lpi_host_solve_batch.restype = ctypes.c_int
+    _lib.lpi_host_solve_batch_cert.restype = ctypes.c_int
     _lib.rollout_host_run.restype = ctypes.c_int
     return _lib
 
@@ -35,8 +36,9 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def lpi_solve(variant, N, m, x0, u0, xref, A, b, Ts, term=None, params=None):
-    """the structured solver of csrc/obca_lpi_core.h on the CPU; arrays as in include/obca_mpc.h"""
+def lpi_solve(variant, N, m, x0, u0, xref, A, b, Ts, term=None, params=None, cert=False):
+    """the structured solver of csrc/obca_lpi_core.h on the CPU; arrays as in include/obca_mpc.h.
+    cert=True adds the certificate buffers (final primal vector "z" and multipliers "y", include/obca_mpc.h)"""
     from oracle import c_oracle
     lib = load()
     x0 = np.ascontiguousarray(x0, float)
@@ -50,9 +52,18 @@ def lpi_solve(variant, N, m, x0, u0, xref, A, b, Ts, term=None, params=None):
             np.ascontiguousarray(A, float).reshape(B, N + 1, M, 2), np.ascontiguousarray(b, float).reshape(B, N + 1, M),
             np.ascontiguousarray(np.broadcast_to(np.asarray(Ts, float), (B,)))]
     marr = (ctypes.c_int * len(m))(*[int(v) for v in m])
-    rc = lib.lpi_host_solve_batch(N, len(m), marr, _ptr(var), B, *[_ptr(a) for a in arrs], _ptr(term),
-                                  ctypes.byref(params), _ptr(out["xopt"]), _ptr(out["uopt"]), _ptr(out["ts_opt"]),
-                                  _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["info"]))
+    extra = []
+    fn = lib.lpi_host_solve_batch
+    if cert:
+        nO = len(m)
+        n_max = (N + 1) * (3 + M + 4 * nO) + 2 * N + 1
+        R_max = 3 + 3 * N + 3 + 2 * (N + 1) + 4 * N + 2 + 2 * (N + 1) * nO + (N + 1) * (M + 4 * nO)
+        out["z"], out["y"] = np.zeros((B, n_max)), np.zeros((B, R_max + 2 * (N + 1) * nO))
+        extra = [_ptr(out["z"]), _ptr(out["y"])]
+        fn = lib.lpi_host_solve_batch_cert
+    rc = fn(N, len(m), marr, _ptr(var), B, *[_ptr(a) for a in arrs], _ptr(term),
+            ctypes.byref(params), _ptr(out["xopt"]), _ptr(out["uopt"]), _ptr(out["ts_opt"]),
+            _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["info"]), *extra)
     assert rc == 0
     return out
 

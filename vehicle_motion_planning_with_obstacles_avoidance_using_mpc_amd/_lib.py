@@ -42,7 +42,7 @@ EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", 
            "obca_set_profile_buffer", "obca_set_mode", "obca_rollouts_create", "obca_rollouts_destroy",
            "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read", "obca_rollouts_run",
            "obca_rollouts_set_mode", "obca_astar_batch", "obca_astar_workspace_bytes", "obca_primal_size", "obca_set_warm_start",
-           "obca_rollouts_set_warm_start")
+           "obca_rollouts_set_warm_start", "obca_dual_size", "obca_set_certificate_buffers")
 
 OBCA_MAX_DYN = 4
 RUN, DONE_GOAL, DONE_CAP, DONE_FAILED = 0, 1, 2, 3
@@ -54,6 +54,30 @@ STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NUMERIC, STATUS_BAD_BOUNDS = -1, -2, -
 _lib = None
 
 
+def _bind_hip_runtime():
+    """libobca_mpc.so names no HIP runtime of its own (no DT_NEEDED entry, see __graft_entry__.build): its hip* symbols
+    bind to the runtime the process already uses, so device memory handed over by the host and our launches always live
+    in ONE runtime, whatever the import order.  Under PyTorch-ROCm that is the copy torch ships (torch/lib/libamdhip64.so,
+    loaded RTLD_LOCAL by torch -- re-opening the same file RTLD_GLOBAL only widens its visibility); without torch, the
+    system runtime.  A C host that links libamdhip64 itself needs nothing of this."""
+    cands = []
+    try:
+        import torch
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except ImportError:
+        pass
+    cands += ["libamdhip64.so.7", "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"]
+    err = None
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+        except OSError as e:
+            err = e
+    raise RuntimeError("no HIP runtime (libamdhip64) could be loaded: %s" % err)
+
+
 def load():
     """Load the shared library (built by __graft_entry__.build()); raises if it is absent."""
     global _lib
@@ -62,10 +86,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libobca_mpc.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(expected at %s). There is no CPU fallback." % LIB_PATH)
-    # PyTorch-ROCm ships its own HIP runtime; libobca_mpc.so is linked against the system one.  Whichever is loaded
-    # first serves both -- load torch's first, always, so that device memory handed over by torch and our launches
-    # live in the same runtime (the other order made hipSetDevice fail in obca_create).
-    import torch  # noqa: F401
+    _bind_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32p = ctypes.c_void_p, ctypes.c_void_p
     lib.obca_create.argtypes = [ctypes.POINTER(ObcaDims), ctypes.POINTER(ctypes.c_void_p)]
@@ -101,6 +122,10 @@ def load():
     lib.obca_primal_size.restype = ctypes.c_int64
     lib.obca_set_warm_start.argtypes = [ctypes.c_void_p, vp, vp, ctypes.c_double]
     lib.obca_set_warm_start.restype = ctypes.c_int
+    lib.obca_dual_size.argtypes = [ctypes.POINTER(ObcaDims)]
+    lib.obca_dual_size.restype = ctypes.c_int64
+    lib.obca_set_certificate_buffers.argtypes = [ctypes.c_void_p, vp, vp]
+    lib.obca_set_certificate_buffers.restype = ctypes.c_int
     lib.obca_rollouts_set_warm_start.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
     lib.obca_rollouts_set_warm_start.restype = ctypes.c_int
     lib.obca_rollouts_read.argtypes = [ctypes.c_void_p] + [vp] * 11

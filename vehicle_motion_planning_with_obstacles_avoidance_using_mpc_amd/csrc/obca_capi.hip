@@ -28,6 +28,7 @@ struct obca_handle {
     double* warm_z;           /* obca_set_warm_start */
     const int32_t* warm_use;
     double warm_mu;
+    double *cert_z, *cert_y;  /* obca_set_certificate_buffers */
     double* ws;               /* lane kernel workspace, allocated on first use */
     size_t ws_stride;
     int* d_offm;
@@ -123,6 +124,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     h->ws_doubles = lpi::carve(d->N, d->n_obs, h->M, h->n_max, h->R_max).total;
     h->prof = nullptr;
     h->warm_z = nullptr; h->warm_use = nullptr; h->warm_mu = 0.0;
+    h->cert_z = nullptr; h->cert_y = nullptr;
     *out = h;
     return OBCA_OK;
 }
@@ -155,6 +157,21 @@ extern "C" int obca_set_warm_start(obca_handle* h, double* z, const int32_t* use
     return OBCA_OK;
 }
 
+extern "C" int64_t obca_dual_size(const obca_dims* d) {
+    if (!dims_ok(d)) return -1;
+    int M = 0;
+    for (int i = 0; i < d->n_obs; ++i) M += d->m[i];
+    int n_max, R_max, io;
+    (void)lds_doubles(d->N, d->n_obs, M, n_max, R_max, io);
+    return (int64_t)R_max + 2 * (int64_t)(d->N + 1) * d->n_obs;
+}
+
+extern "C" int obca_set_certificate_buffers(obca_handle* h, double* z, double* y) {
+    if (!h) return OBCA_E_INVAL;
+    h->cert_z = z; h->cert_y = y;
+    return OBCA_OK;
+}
+
 extern "C" void obca_set_profile_buffer(obca_handle* h, double* prof) { if (h) h->prof = prof; }
 
 int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
@@ -174,6 +191,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     L.variant = variant; L.x0 = x0; L.u0 = u0; L.xref = xref; L.A = A; L.b = b; L.Ts = Ts; L.term = term;
     L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info; L.prof = h->prof;
     L.warm_z = h->warm_z; L.warm_use = h->warm_use; L.warm_mu = h->warm_mu;
+    L.cert_z = h->cert_z; L.cert_y = h->cert_y;
     auto cpw = [](ObcaWeightsDev& d, const obca_weights& s) {
         // the reference's double loops use Q[i,j] for every (i,j): only the symmetric part matters
         for (int a = 0; a < 3; ++a)

@@ -63,6 +63,8 @@ struct ObcaLaunch {
     double* warm_z;        /* [B,n_max] primal vector of the last successful solve (in/out) or NULL: obca_set_warm_start */
     const int32_t* warm_use; /* [B] != 0: start from warm_z shifted by one stage; NULL = every instance          */
     double warm_mu;        /* barrier parameter a warm-started solve begins with                                 */
+    double* cert_z;        /* [B,n_max] final primal vector, or NULL: obca_set_certificate_buffers                        */
+    double* cert_y;        /* [B,R_max + 2 npair] final multipliers (objective units), rows then rotation equalities, or NULL */
     ObcaParamsDev prm;
 };
 

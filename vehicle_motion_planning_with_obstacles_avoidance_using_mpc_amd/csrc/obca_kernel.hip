@@ -1699,6 +1699,17 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
         double* zp = A.warm_z + (size_t)inst * A.n_max;        // kept for the next solve of this instance
         for (int t = lane; t < L.n; t += NT) zp[t] = S.x[t];
     }
+    // ---- certificate output (obca_set_certificate_buffers): primal vector and multipliers in objective units
+    if (A.cert_z != nullptr) {
+        double* zc = A.cert_z + (size_t)inst * A.n_max;
+        for (int t = lane; t < L.n; t += NT) zc[t] = S.x[t];
+    }
+    if (A.cert_y != nullptr) {
+        double* yc = A.cert_y + (size_t)inst * (A.R_max + 2 * L.npair);
+        const double isf = 1.0 / sf;
+        for (int r = lane; r < L.R; r += NT) yc[r] = S.y[r] * isf;
+        for (int t = lane; t < 2 * L.npair; t += NT) yc[L.R + t] = S.nu[t] * isf;
+    }
     // ---- outputs (last iterate on failure, like the reference's except-branch) --------------------------------
     {
         const int N1 = L.N + 1;

@@ -987,7 +987,7 @@ LPI_FN double row_barrier_lpi(double lo, double up, bool eq, double s, double p,
 }
 
 // ---------------------------------------------------------------- one instance, start to finish
-struct Out { int status, iters, nfact; double f, elastic, E0, ts_opt; };
+struct Out { int status, iters, nfact; double f, elastic, E0, ts_opt, sf; };
 
 // zwarm != nullptr: start from that primal vector moved one stage forward (last stage repeated) with barrier
 // parameter mu_warm (obca_set_warm_start); otherwise the reference's cold start
@@ -1276,6 +1276,7 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
         o.status = OBCA_STATUS_INFEASIBLE;
     o.iters = it;
     o.f = f / sf;
+    o.sf = sf;
     o.ts_opt = L.free_T ? S.x[L.iT()] * in.Ts : in.Ts;
     return o;
 }
@@ -1355,6 +1356,16 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     if (A.warm_z != nullptr && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE)) {
         double* zp = A.warm_z + inst * (size_t)A.n_max;
         for (int t = 0; t < L.n; ++t) zp[t] = S.x[t];
+    }
+    if (A.cert_z != nullptr) {
+        double* zc = A.cert_z + inst * (size_t)A.n_max;
+        for (int t = 0; t < L.n; ++t) zc[t] = S.x[t];
+    }
+    if (A.cert_y != nullptr) {
+        double* yc = A.cert_y + inst * (size_t)(A.R_max + 2 * L.npair);
+        const double isf = 1.0 / o.sf;
+        for (int r = 0; r < L.R; ++r) yc[r] = S.y[r] * isf;
+        for (int t = 0; t < 2 * L.npair; ++t) yc[L.R + t] = S.nu[t] * isf;
     }
     double* xo = A.xopt + inst * 3 * N1;
     double* uo = A.uopt + inst * 2 * L.N;

@@ -8,6 +8,7 @@ pose is in collision, or whose time-scale bound ``max_Topt`` (signed sum, src/ob
 the window length, are redrawn from the same generator, so the batch is reproducible from ``seed0`` alone.
 """
 import math
+import os
 
 import numpy as np
 
@@ -191,12 +192,12 @@ def make_instance_c3(i, N=20, seed0=SEED0 + 10 ** 6, sense_dis=10.0):
         i0 = int(rng.integers(0, path.shape[1] - N - 1))
         x0 = path[:, i0] + noise
         xref = window(path, x0, N)
-        if clearance(x0, box) < DMIN + 0.15 or clearance(xref[:, N], box) < DMIN + 0.15:
-            continue
         dis = (xref[0, N] - x0[0]) + (xref[1, N] - x0[1])
         seg = np.diff(xref[:2], axis=1)
         length = float(np.sum(np.hypot(seg[0], seg[1])))
         if dis / (N * V_MAX * TS) + 1.0 < 1.15 * length / (N * V_MAX * TS):
+            continue
+        if clearance(x0, box) < DMIN + 0.15 or clearance(xref[:, N], box) < DMIN + 0.15:     # (the expensive test last)
             continue
         rect = rectangle_vertices(box[0], box[1], 0.0, box[2], box[3])
         static = [[[39, 9], [0, 9]], rect, [[0, 1], [39, 1]]]
@@ -224,18 +225,50 @@ def make_instance_c3(i, N=20, seed0=SEED0 + 10 ** 6, sense_dis=10.0):
     raise RuntimeError("could not draw a C3 instance for seed %d" % (seed0 + i))
 
 
-def make_batch_c3(B, N=20, first=0, gated=True):
-    """gated=True: the fixed-time sub-batch (5 obstacles, variant 6); False: the free-time one (3 static, variant 4)."""
-    ins, i = [], first
-    while len(ins) < B:
+def _c3_chunk(args):
+    first, count, N = args
+    out = []
+    for i in range(first, first + count):
         try:
-            q = make_instance_c3(i, N)
+            out.append((i, make_instance_c3(i, N)))
         except RuntimeError:                 # no admissible window for this seed: the seed is skipped
-            i += 1
-            continue
+            pass
+    return out
+
+
+def make_batch_c3(B, N=20, first=0, gated=True, procs=1):
+    """gated=True: the fixed-time sub-batch (5 obstacles, variant 6); False: the free-time one (3 static, variant 4).
+    Instances are the seeds first, first+1, ... whose lidar gate matches, in seed order; procs > 1 draws them in that
+    many worker processes (same result -- every instance depends on its own seed only)."""
+    ins, i = [], first
+    if procs > 1:
+        # worker PROCESSES started from scratch (python -m ...scenarios): never a fork of a process that holds a HIP
+        # context, and no dependence on how the caller's __main__ was started
+        import pickle
+        import subprocess
+        import sys
+        import tempfile
+        chunk = 64
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        with tempfile.TemporaryDirectory() as tmp:
+            while len(ins) < B:
+                jobs = []
+                for j in range(procs):
+                    out = os.path.join(tmp, "c3_%d.pkl" % j)
+                    jobs.append((out, subprocess.Popen([sys.executable, "-m", __name__, "c3", str(i + j * chunk), str(chunk),
+                                                        str(N), out], cwd=root)))
+                i += procs * chunk
+                for out, pr in jobs:
+                    if pr.wait() != 0:
+                        raise RuntimeError("scenario worker failed")
+                    with open(out, "rb") as f:
+                        ins += [q for _, q in pickle.load(f) if q["gated"] == gated]
+        ins = ins[:B]
+    while len(ins) < B:
+        part = _c3_chunk((i, 1, N))
         i += 1
-        if q["gated"] == gated:
-            ins.append(q)
+        if part and part[0][1]["gated"] == gated:
+            ins.append(part[0][1])
     if gated:
         m = ins[0]["m"]
         A = np.stack([q["A"] for q in ins])
@@ -302,3 +335,11 @@ def make_world_c5(i, n_dyn=2, seed0=SEED0 + 2 * 10 ** 6):
         return problemSetting.from_world((39, 10), start, goal, static, grid, dyn, [[25, 39], [1, 9]], ref_path=path,
                                          name="c5_%d" % i)
     raise RuntimeError("could not draw a C5 world for seed %d" % (seed0 + i))
+
+
+if __name__ == "__main__":          # worker of make_batch_c3(procs > 1): python -m ...scenarios c3 FIRST COUNT N OUT
+    import pickle
+    import sys
+    if len(sys.argv) == 6 and sys.argv[1] == "c3":
+        with open(sys.argv[5], "wb") as f:
+            pickle.dump(_c3_chunk((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))), f)

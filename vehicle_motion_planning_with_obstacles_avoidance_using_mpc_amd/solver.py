@@ -91,6 +91,20 @@ class BatchSolver:
         'lane' (64 instances per wavefront, HBM workspace)"""
         _lib.check(self.lib.obca_set_mode(self._h, self.MODES.get(mode, mode)))
 
+    def enable_certificates(self, on=True):
+        """Keep the final primal vector and multipliers of every solve (include/obca_mpc.h, obca_set_certificate_buffers):
+        after a solve ``self.cert_z[:B]`` is [B, primal_size] and ``self.cert_y[:B]`` is [B, dual_size]."""
+        if on:
+            nz = int(self.lib.obca_primal_size(ctypes.byref(self._dims)))
+            ny = int(self.lib.obca_dual_size(ctypes.byref(self._dims)))
+            self.cert_z = torch.zeros(self.max_batch, nz, dtype=torch.float64, device=self.device)
+            self.cert_y = torch.zeros(self.max_batch, ny, dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.obca_set_certificate_buffers(self._h, ctypes.c_void_p(self.cert_z.data_ptr()),
+                                                             ctypes.c_void_p(self.cert_y.data_ptr())))
+        else:
+            _lib.check(self.lib.obca_set_certificate_buffers(self._h, None, None))
+            self.cert_z = self.cert_y = None
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.obca_destroy(self._h)
