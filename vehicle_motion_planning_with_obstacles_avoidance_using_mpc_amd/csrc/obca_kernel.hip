@@ -1179,10 +1179,47 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
 }  // namespace
 
 // ================================================================== the kernel
-template <int RPL>
-__device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int inst, const int pass) {
+// The scalar part of a launch descriptor as wave-uniform values.  obca_solve_batch hands the descriptor over as a kernel
+// argument (scalar registers from the start); the fused closed-loop kernel reads it from HBM with vector loads, and
+// without the readfirstlane below every field -- 20 pointers, the shape -- would sit in vector registers for the whole
+// solve (measured: 1.1 KB of scratch per lane).
+template <bool FROM_MEMORY> __device__ __forceinline__ int uni(int v) { return FROM_MEMORY ? __builtin_amdgcn_readfirstlane(v) : v; }
+template <bool FROM_MEMORY, class T> __device__ __forceinline__ T* uni(T* p) {
+    if (!FROM_MEMORY) return p;
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+template <bool FROM_MEMORY> __device__ __forceinline__ double uni(double v) { return FROM_MEMORY ? lane_read(v, 0) : v; }
+struct ObcaHead {
+    int32_t B, N, nO, M, n_max, R_max, inst_off;
+    const int32_t* variant;
+    const double *x0, *u0, *xref, *A, *b, *Ts, *term;
+    double *xopt, *uopt, *ts_opt;
+    int32_t *status, *iters;
+    double *info, *prof, *warm_z;
+    const int32_t* warm_use;
+    double warm_mu;
+    double *cert_z, *cert_y;
+};
+
+typedef const __attribute__((address_space(4))) ObcaLaunch ObcaLaunchConst;   // descriptor in HBM, read through the scalar cache
+
+template <int RPL, bool FROM_MEMORY = false, class DESC = const ObcaLaunch>
+__device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const int pass) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
+    ObcaHead A;
+    {
+        constexpr bool U = FROM_MEMORY;
+        A.B = uni<U>(Ain.B); A.N = uni<U>(Ain.N); A.nO = uni<U>(Ain.nO); A.M = uni<U>(Ain.M); A.n_max = uni<U>(Ain.n_max);
+        A.R_max = uni<U>(Ain.R_max); A.inst_off = uni<U>(Ain.inst_off);
+        A.variant = uni<U>(Ain.variant); A.x0 = uni<U>(Ain.x0); A.u0 = uni<U>(Ain.u0); A.xref = uni<U>(Ain.xref); A.A = uni<U>(Ain.A);
+        A.b = uni<U>(Ain.b); A.Ts = uni<U>(Ain.Ts); A.term = uni<U>(Ain.term); A.xopt = uni<U>(Ain.xopt); A.uopt = uni<U>(Ain.uopt);
+        A.ts_opt = uni<U>(Ain.ts_opt); A.status = uni<U>(Ain.status); A.iters = uni<U>(Ain.iters); A.info = uni<U>(Ain.info);
+        A.prof = uni<U>(Ain.prof); A.warm_z = uni<U>(Ain.warm_z); A.warm_use = uni<U>(Ain.warm_use); A.warm_mu = uni<U>(Ain.warm_mu);
+        A.cert_z = uni<U>(Ain.cert_z); A.cert_y = uni<U>(Ain.cert_y);
+    }
     if (inst >= A.B) return;
     if (A.variant[inst] == 0) {                      // masked out by the caller (device-side closed loop)
         if (lane == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; }
@@ -1241,16 +1278,16 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     Inst& in = *reinterpret_cast<Inst*>(smem + A.inst_off);
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i <= OBCA_MAX_OBST; ++i) S.offm[i] = A.offm[i];     // static indices: A stays in kernarg
+        for (int i = 0; i <= OBCA_MAX_OBST; ++i) S.offm[i] = Ain.offm[i];     // static indices: A stays in kernarg
     }
 
     // ---- instance data ----------------------------------------------------------------------------------
     if (lane == 0) {
         const bool fr = L.free_T != 0;
-        for (int j = 0; j < 9; ++j) { in.Q[j] = fr ? A.prm.free_time.Q[j] : A.prm.fixed_time.Q[j]; in.P[j] = fr ? A.prm.free_time.P[j] : A.prm.fixed_time.P[j]; }
-        for (int j = 0; j < 4; ++j) { in.R1[j] = fr ? A.prm.free_time.R1[j] : A.prm.fixed_time.R1[j]; in.R2[j] = fr ? A.prm.free_time.R2[j] : A.prm.fixed_time.R2[j]; in.gego[j] = A.prm.gego[j]; }
-        for (int j = 0; j < 2; ++j) { in.xL[j] = A.prm.xL[j]; in.xU[j] = A.prm.xU[j]; in.uL[j] = A.prm.uL[j]; in.uU[j] = A.prm.uU[j]; }
-        in.off = A.prm.off; in.dmin = A.prm.dmin;
+        for (int j = 0; j < 9; ++j) { in.Q[j] = fr ? Ain.prm.free_time.Q[j] : Ain.prm.fixed_time.Q[j]; in.P[j] = fr ? Ain.prm.free_time.P[j] : Ain.prm.fixed_time.P[j]; }
+        for (int j = 0; j < 4; ++j) { in.R1[j] = fr ? Ain.prm.free_time.R1[j] : Ain.prm.fixed_time.R1[j]; in.R2[j] = fr ? Ain.prm.free_time.R2[j] : Ain.prm.fixed_time.R2[j]; in.gego[j] = Ain.prm.gego[j]; }
+        for (int j = 0; j < 2; ++j) { in.xL[j] = Ain.prm.xL[j]; in.xU[j] = Ain.prm.xU[j]; in.uL[j] = Ain.prm.uL[j]; in.uU[j] = Ain.prm.uU[j]; }
+        in.off = Ain.prm.off; in.dmin = Ain.prm.dmin;
         for (int j = 0; j < 3; ++j) in.x0[j] = A.x0[(size_t)inst * 3 + j];
         for (int j = 0; j < 2; ++j) in.u0[j] = A.u0[(size_t)inst * 2 + j];
         in.Ts = A.Ts[inst];
@@ -1277,7 +1314,8 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     }
     SYNC();
 
-    const ObcaOptsDev O = A.prm.opt;          // by value: A may live in HBM (fused closed-loop kernel); the descriptor of
+    ObcaOptsDev O;
+    O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed;          // by value: A may live in HBM (fused closed-loop kernel); the descriptor of
                                               // an escalated pass carries rho x 100 itself
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
@@ -1695,6 +1733,15 @@ __device__ __forceinline__ void obca_ipm_body(const ObcaLaunch& A, const int ins
     if ((status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE) && elastic_max > O.feas_tol)
         status = OBCA_STATUS_INFEASIBLE;
 
+    if (FROM_MEMORY) {
+        // the output side of the descriptor is read again here instead of being carried through the solve in registers
+        __asm__ volatile("" ::: "memory");
+        constexpr bool U = FROM_MEMORY;
+        A.n_max = uni<U>(Ain.n_max); A.R_max = uni<U>(Ain.R_max);
+        A.xopt = uni<U>(Ain.xopt); A.uopt = uni<U>(Ain.uopt); A.ts_opt = uni<U>(Ain.ts_opt); A.status = uni<U>(Ain.status);
+        A.iters = uni<U>(Ain.iters); A.info = uni<U>(Ain.info); A.warm_z = uni<U>(Ain.warm_z);
+        A.cert_z = uni<U>(Ain.cert_z); A.cert_y = uni<U>(Ain.cert_y);
+    }
     if (A.warm_z != nullptr && (status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE)) {
         double* zp = A.warm_z + (size_t)inst * A.n_max;        // kept for the next solve of this instance
         for (int t = lane; t < L.n; t += NT) zp[t] = S.x[t];
@@ -1756,15 +1803,32 @@ extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A
 // is the descriptor obca_solve_batch would use for problem shape g (= sensed moving obstacles), a = 1 the retry.
 #include "obca_rollout_core.h"
 
+// The harness runs once per step on lane 0; kept OUT of line so that nothing of it (the ~100 pointers of rollout::Dev,
+// its vertex arrays) is hoisted out of the step loop and kept alive in registers across the solve.
+__device__ __noinline__ void ro_prepare(const rollout::Dev* D, int b) { rollout::prepare(*D, b); }
+__device__ __noinline__ void ro_finish(const rollout::Dev* D, int b) { rollout::finish(*D, b); }
+__device__ __noinline__ int ro_retry(const rollout::Dev* D, int g, int b) { rollout::make_retry(*D, g, b); return D->var8[g][b]; }
+__device__ __noinline__ int ro_flag_sel(const rollout::Dev* D, int b, int* sel) { *sel = D->sel[b]; return D->flags[b]; }
+
 template <int RPL>
-__device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* __restrict__ launches, int n_steps) {
+__device__ __noinline__ void solve_out_of_line(const ObcaLaunch* Lp, int b, int pass) { obca_ipm_body<RPL, true>(*Lp, b, pass); }
+
+template <int RPL>
+__device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* launches, int n_steps) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= D.B) return;
+    __shared__ int ro_msg[2];
     for (int step = 0; step < n_steps; ++step) {
-        if (lane == 0) rollout::prepare(D, b);
+        if (lane == 0) {
+            ro_prepare(&D, b);
+            int sel;
+            ro_msg[0] = ro_flag_sel(&D, b, &sel);
+            ro_msg[1] = sel;
+        }
         __syncthreads();
-        if (D.flags[b] != OBCA_RUN) break;
-        const int g = D.sel[b];
+        if (ro_msg[0] != OBCA_RUN) break;
+        const int g = __builtin_amdgcn_readfirstlane(ro_msg[1]);     // wave-uniform: the descriptor is read with scalar loads
+        __syncthreads();
         for (int attempt = 0; attempt < 2; ++attempt) {
             // second attempt: obca_mpc4 -> the escalated pass (rho x 100; returns at once unless the first pass ended
             // "infeasible"); obca_mpc6 -> obca_mpc8 where obca_mpc6 failed.  One call site: the body is inlined once.
@@ -1772,31 +1836,33 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
             if (attempt == 1) {
                 if (g == 0) Lp = launches + 2 * rollout::MAX_GROUPS;
                 else {
-                    if (lane == 0) rollout::make_retry(D, g, b);
+                    if (lane == 0) ro_msg[0] = ro_retry(&D, g, b);
                     __syncthreads();
-                    if (D.var8[g][b] != 8) break;
+                    const int v8 = ro_msg[0];
+                    __syncthreads();
+                    if (v8 != 8) break;
                     Lp = launches + g + rollout::MAX_GROUPS;
                 }
             }
-            obca_ipm_body<RPL>(*Lp, b, (attempt == 1 && g == 0) ? 1 : 0);
+            obca_ipm_body<RPL, false, ObcaLaunchConst>(*(ObcaLaunchConst*)Lp, b, (attempt == 1 && g == 0) ? 1 : 0);
             __syncthreads();
         }
-        if (lane == 0) rollout::finish(D, b);
+        if (lane == 0) ro_finish(&D, b);
         __syncthreads();
     }
 }
 
 // _r4: every shape of the rollout has <= 256 rows (static obstacles only at N=5); _r6: <= 384 rows
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r4(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
+obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps) {
     rollout_fused_body<4>(*Dp, launches, n_steps);
 }
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r5(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
+obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps) {
     rollout_fused_body<5>(*Dp, launches, n_steps);
 }
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r6(const rollout::Dev* __restrict__ Dp, const ObcaLaunch* __restrict__ launches, int n_steps) {
+obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps) {
     rollout_fused_body<6>(*Dp, launches, n_steps);
 }
 
