@@ -61,6 +61,8 @@ typedef struct obca_params {
     double feas_tol;                   /* [1e-6]  largest elastic variable still called feasible   */
     int32_t max_iter_free;             /* [3000]  IPOPT default, variant 4                         */
     int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8                       */
+    int32_t max_soc;                   /* [4]     IPOPT max_soc: second-order-correction trials after a rejected first
+                                                   trial step; 0 = the default, negative = off              */
 } obca_params;
 
 typedef struct obca_handle obca_handle;

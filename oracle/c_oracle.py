@@ -15,7 +15,8 @@ class OracleParams(ctypes.Structure):
                                                       ("R1x", 4), ("R2x", 4), ("xL", 2), ("xU", 2), ("uL", 2), ("uU", 2),
                                                       ("ego", 4))] + \
                [("dmin", ctypes.c_double), ("tol", ctypes.c_double), ("rho", ctypes.c_double),
-                ("feas_tol", ctypes.c_double), ("max_iter_free", ctypes.c_int), ("max_iter_fixed", ctypes.c_int)]
+                ("feas_tol", ctypes.c_double), ("max_iter_free", ctypes.c_int), ("max_iter_fixed", ctypes.c_int),
+                ("max_soc", ctypes.c_int)]          # 0 = IPOPT's default (4 second-order-correction trials), < 0 = off
 
 
 _lib = None
@@ -58,6 +59,7 @@ def default_params(**kw):
     p.feas_tol = float(kw.get("feas_tol", 0.0))
     p.max_iter_free = int(kw.get("max_iter_free", 0))
     p.max_iter_fixed = int(kw.get("max_iter_fixed", 0))
+    p.max_soc = int(kw.get("max_soc", 0))
     return p
 
 

@@ -351,7 +351,7 @@ static void bk_solve(const double* A, int n, const int* piv, double* b) {
 /* ------------------------------------------------------------------------------------------------------ */
 typedef struct {
     double tol, rho, feas_tol;
-    int max_iter_free, max_iter_fixed;
+    int max_iter_free, max_iter_fixed, max_soc;
 } Opts;
 
 #define MU_INIT 0.1
@@ -362,6 +362,7 @@ typedef struct {
 #define BPUSH 1e-2
 #define KAPPA_D 1e-5
 #define KAPPA_SIGMA 1e10
+#define KAPPA_SOC 0.99
 #define S_MAX 100.0
 #define GAMMA_THETA 1e-5
 #define GAMMA_PHI 1e-8
@@ -385,7 +386,7 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
     const int n = p->n, mh = p->mh, me = p->me, na = p->naug, N = p->N;
     const int nk = n + mh + na;
     /* T rows carry multiplicity N+1 in the dense layout by being repeated (like oracle/obca_nlp.py) */
-    size_t dbl = (size_t)n * 8 + (size_t)me * 24 + (size_t)mh * 4 + (size_t)me * n + (size_t)mh * n + (size_t)n * n +
+    size_t dbl = (size_t)n * 10 + (size_t)me * 29 + (size_t)mh * 7 + (size_t)me * n + (size_t)mh * n + (size_t)n * n +
                  (size_t)nk * nk + (size_t)nk * 2 + 64;
     double* mem = (double*)calloc(dbl, sizeof(double));
     int* piv = (int*)malloc(sizeof(int) * nk);
@@ -398,6 +399,8 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
     double *ge = TAKE(me), *lb = TAKE(me), *ub = TAKE(me), *E = TAKE(me), *gh = TAKE(me), *dy = TAKE(me), *get = TAKE(me);
     double *Ds = TAKE(me), *Dp = TAKE(me), *Dn = TAKE(me), *rs = TAKE(me), *rp = TAKE(me), *rn = TAKE(me), *gs = TAKE(me);
     double *st_ = TAKE(me), *pt_ = TAKE(me);
+    double *nt_ = TAKE(me), *gsoc = TAKE(me), *ghs = TAKE(me), *dys = TAKE(me), *get2 = TAKE(me);
+    double *csoc = TAKE(mh), *dyhs = TAKE(mh), *cht2 = TAKE(mh), *dxs = TAKE(n), *xt2 = TAKE(n);
     double *yh = TAKE(mh), *dyh = TAKE(mh), *ch = TAKE(mh), *cht = TAKE(mh);
     double *Je = TAKE((size_t)me * n), *Jh = TAKE((size_t)mh * n), *W = TAKE((size_t)n * n), *K = TAKE((size_t)nk * nk), *rhs = TAKE(nk), *sol = TAKE(nk);
     (void)gt_; (void)tmpn;
@@ -598,7 +601,8 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
                 alpha_min = GAMMA_ALPHA * c;
             } else alpha_min = GAMMA_ALPHA * GAMMA_THETA;
             double alpha = a_max;
-            int accepted = 0, aug = 0;
+            int accepted = 0, aug = 0, first_trial = 1, use_soc = 0;
+            double a_used = a_max;
             for (;;) {
                 for (int i = 0; i < n; ++i) xt[i] = x[i] + alpha * dx[i];
                 const double ft = sf * objective(p, xt, NULL, NULL);
@@ -610,6 +614,7 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
                     const int hasL = !eq[r] && lb[r] > -INF, hasU = !eq[r] && ub[r] < INF;
                     const double sv = eq[r] ? 0 : s[r] + alpha * (dy[r] - rs[r]) / Ds[r];
                     const double pv = ep[r] + alpha * (dy[r] - rp[r]) / Dp[r], nv = en[r] + alpha * (-dy[r] - rn[r]) / Dn[r];
+                    st_[r] = sv; pt_[r] = pv; nt_[r] = nv;
                     th_t += fabs(get[r] - sv - pv + nv);
                     phi_t += rho * (pv + nv) - mu * (log(pv) + log(nv));
                     if (hasL) { phi_t -= mu * log(sv - lb[r]); if (!hasU) phi_t += KAPPA_D * mu * (sv - lb[r]); }
@@ -624,7 +629,82 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
                     if (th <= theta_min && sw) ok = phi_t <= phi + ETA_PHI * alpha * dphi + 10 * 2.220446049250313e-16 * fabs(phi);
                     else { ok = (th_t <= (1 - GAMMA_THETA) * th) || (phi_t <= phi - GAMMA_PHI * th); aug = ok; }
                 }
-                if (ok) { accepted = 1; break; }
+                if (ok) { accepted = 1; a_used = alpha; break; }
+                /* second-order correction (IPOPT max_soc = 4, kappa_soc = 0.99): only after the FIRST trial step, and only
+                   when it did not reduce the constraint violation; same matrix (same delta_w), corrected right-hand side */
+                int evals_finite = isfinite(ft);
+                for (int r = 0; r < me && evals_finite; ++r) if (!isfinite(get[r])) evals_finite = 0;
+                for (int r = 0; r < mh && evals_finite; ++r) if (!isfinite(cht[r])) evals_finite = 0;
+                if (first_trial && o->max_soc > 0 && th_t >= th && evals_finite) {
+                    for (int r = 0; r < mh; ++r) csoc[r] = alpha * ch[r] + cht[r];
+                    for (int r = 0; r < me; ++r) gsoc[r] = alpha * (ge[r] - s[r] - ep[r] + en[r]) + (get[r] - st_[r] - pt_[r] + nt_[r]);
+                    double th_old = th_t;
+                    for (int ps = 0; ps < o->max_soc; ++ps) {
+                        for (int r = 0; r < me; ++r)
+                            ghs[r] = gsoc[r] + (eq[r] ? 0 : rs[r] / Ds[r]) + rp[r] / Dp[r] - rn[r] / Dn[r];
+                        for (int i = 0; i < n; ++i) sol[i] = -rx[i];
+                        for (int r = na; r < me; ++r) {
+                            const double* Jr = Je + (size_t)r * n;
+                            const double ei = 1 / E[r];
+                            for (int i = 0; i < n; ++i) {
+                                if (Jr[i] == 0) continue;
+                                const double v = Jr[i] * ei;
+                                sol[i] -= v * ghs[r];
+                            }
+                        }
+                        for (int r = 0; r < mh; ++r) sol[n + r] = -csoc[r];
+                        for (int r = 0; r < na; ++r) sol[n + mh + r] = -ghs[r];
+                        bk_solve(K, nk, piv, sol);
+                        memcpy(dxs, sol, sizeof(double) * n);
+                        memcpy(dyhs, sol + n, sizeof(double) * mh);
+                        double a_soc = 1;
+                        for (int r = 0; r < me; ++r) {
+                            if (r < na) dys[r] = sol[n + mh + r];
+                            else { double v = ghs[r]; const double* Jr = Je + (size_t)r * n; for (int i = 0; i < n; ++i) v += Jr[i] * dxs[i]; dys[r] = v / E[r]; }
+                            const int hasL = !eq[r] && lb[r] > -INF, hasU = !eq[r] && ub[r] < INF;
+                            const double ds = eq[r] ? 0 : (dys[r] - rs[r]) / Ds[r], dp = (dys[r] - rp[r]) / Dp[r], dn = (-dys[r] - rn[r]) / Dn[r];
+                            if (hasL && ds < 0) a_soc = fmin(a_soc, -tau * (s[r] - lb[r]) / ds);
+                            if (hasU && ds > 0) a_soc = fmin(a_soc, tau * (ub[r] - s[r]) / ds);
+                            if (dp < 0) a_soc = fmin(a_soc, -tau * ep[r] / dp);
+                            if (dn < 0) a_soc = fmin(a_soc, -tau * en[r] / dn);
+                        }
+                        for (int i = 0; i < n; ++i) xt2[i] = x[i] + a_soc * dxs[i];
+                        const double fs = sf * objective(p, xt2, NULL, NULL);
+                        elastic_rows(p, xt2, get2, NULL, NULL, NULL, NULL, NULL);
+                        hard_rows(p, xt2, cht2, NULL, NULL, NULL);
+                        int fin = isfinite(fs);
+                        for (int r = 0; r < me && fin; ++r) if (!isfinite(get2[r])) fin = 0;
+                        for (int r = 0; r < mh && fin; ++r) if (!isfinite(cht2[r])) fin = 0;
+                        double th_s = 0, phi_s = fs;
+                        for (int r = 0; r < mh; ++r) th_s += fabs(cht2[r]);
+                        for (int r = 0; r < me; ++r) {
+                            const int hasL = !eq[r] && lb[r] > -INF, hasU = !eq[r] && ub[r] < INF;
+                            const double sv = eq[r] ? 0 : s[r] + a_soc * (dys[r] - rs[r]) / Ds[r];
+                            const double pv = ep[r] + a_soc * (dys[r] - rp[r]) / Dp[r], nv = en[r] + a_soc * (-dys[r] - rn[r]) / Dn[r];
+                            st_[r] = sv; pt_[r] = pv; nt_[r] = nv;
+                            th_s += fabs(get2[r] - sv - pv + nv);
+                            phi_s += rho * (pv + nv) - mu * (log(pv) + log(nv));
+                            if (hasL) { phi_s -= mu * log(sv - lb[r]); if (!hasU) phi_s += KAPPA_D * mu * (sv - lb[r]); }
+                            if (hasU) { phi_s -= mu * log(ub[r] - sv); if (!hasL) phi_s += KAPPA_D * mu * (ub[r] - sv); }
+                        }
+                        if (!fin) { th_s = INF; phi_s = INF; }
+                        int ok_s = 0, aug_s = 0;
+                        int blk = th_s >= theta_max;
+                        for (int i = 0; i < nfilt && !blk; ++i) if (th_s >= filt_t[i] && phi_s >= filt_p[i]) blk = 1;
+                        if (isfinite(phi_s) && isfinite(th_s) && !blk) {
+                            const int sw = dphi < 0 && alpha * pow(-dphi, S_PHI) > pow(th, S_THETA);
+                            if (th <= theta_min && sw) ok_s = phi_s <= phi + ETA_PHI * alpha * dphi + 10 * 2.220446049250313e-16 * fabs(phi);
+                            else { ok_s = (th_s <= (1 - GAMMA_THETA) * th) || (phi_s <= phi - GAMMA_PHI * th); aug_s = ok_s; }
+                        }
+                        if (ok_s) { accepted = 1; use_soc = 1; aug = aug_s; a_used = a_soc; break; }
+                        if (!fin || th_s > KAPPA_SOC * th_old) break;
+                        th_old = th_s;
+                        for (int r = 0; r < mh; ++r) csoc[r] = a_soc * csoc[r] + cht2[r];
+                        for (int r = 0; r < me; ++r) gsoc[r] = a_soc * gsoc[r] + (get2[r] - st_[r] - pt_[r] + nt_[r]);
+                    }
+                    if (accepted) break;
+                }
+                first_trial = 0;
                 alpha *= 0.5;
                 if (alpha < alpha_min) break;
             }
@@ -639,18 +719,22 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
             }
             for (int r = 0; r < me; ++r) {
                 const int hasL = !eq[r] && lb[r] > -INF, hasU = !eq[r] && ub[r] < INF;
+                /* the bound multipliers always follow the ORIGINAL direction (step a_z); the primal variables and y the
+                   accepted one -- the second-order-corrected direction with its own step length when that was taken */
                 const double ds = eq[r] ? 0 : (dy[r] - rs[r]) / Ds[r], dp = (dy[r] - rp[r]) / Dp[r], dn = (-dy[r] - rn[r]) / Dn[r];
+                const double dyu = use_soc ? dys[r] : dy[r];
+                const double dsu = eq[r] ? 0 : (dyu - rs[r]) / Ds[r], dpu = (dyu - rp[r]) / Dp[r], dnu = (-dyu - rn[r]) / Dn[r];
                 const double so = s[r], po = ep[r], no = en[r];
-                s[r] = eq[r] ? 0 : so + alpha * ds; ep[r] = po + alpha * dp; en[r] = no + alpha * dn;
+                s[r] = eq[r] ? 0 : so + a_used * dsu; ep[r] = po + a_used * dpu; en[r] = no + a_used * dnu;
                 if (hasL) { const double z = zL[r] + a_z * ((mu - zL[r] * ds) / (so - lb[r]) - zL[r]), sl = s[r] - lb[r]; zL[r] = fmax(fmin(z, KAPPA_SIGMA * mu / sl), mu / (KAPPA_SIGMA * sl)); }
                 if (hasU) { const double z = zU[r] + a_z * ((mu + zU[r] * ds) / (ub[r] - so) - zU[r]), su = ub[r] - s[r]; zU[r] = fmax(fmin(z, KAPPA_SIGMA * mu / su), mu / (KAPPA_SIGMA * su)); }
                 const double z1 = zp[r] + a_z * ((mu - zp[r] * dp) / po - zp[r]), z2 = zn[r] + a_z * ((mu - zn[r] * dn) / no - zn[r]);
                 zp[r] = fmax(fmin(z1, KAPPA_SIGMA * mu / ep[r]), mu / (KAPPA_SIGMA * ep[r]));
                 zn[r] = fmax(fmin(z2, KAPPA_SIGMA * mu / en[r]), mu / (KAPPA_SIGMA * en[r]));
-                y[r] += alpha * dy[r];
+                y[r] += a_used * dyu;
             }
-            for (int r = 0; r < mh; ++r) yh[r] += alpha * dyh[r];
-            memcpy(x, xt, sizeof(double) * n);
+            for (int r = 0; r < mh; ++r) yh[r] += a_used * (use_soc ? dyhs[r] : dyh[r]);
+            memcpy(x, use_soc ? xt2 : xt, sizeof(double) * n);
             fprev = fobj; have_prev = 1;
         }
     }
@@ -660,7 +744,7 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
     *ts = p->freeT ? x[iT(p)] * p->Ts : p->Ts;
     *iters = it;
     if (info) { info[0] = objective(p, x, NULL, NULL); info[1] = elastic; info[2] = E0; info[3] = nfact; }
-    (void)st_; (void)pt_; (void)bx;
+    (void)bx;
     free(mem); free(piv); free(eq);
     return status;
 }
@@ -669,6 +753,7 @@ typedef struct {
     double Qf[9], Pf[9], R1f[4], R2f[4], Qx[9], Px[9], R1x[4], R2x[4];
     double xL[2], xU[2], uL[2], uU[2], ego[4], dmin, tol, rho, feas_tol;
     int max_iter_free, max_iter_fixed;
+    int max_soc;                            /* 0 = IPOPT's default (4), negative = off */
 } OracleParams;
 
 static void sym(double* d, const double* s, int k) { for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) d[k * a + b] = 0.5 * (s[k * a + b] + s[k * b + a]); }
@@ -721,6 +806,7 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         Opts o;
         o.tol = prm->tol > 0 ? prm->tol : 1e-8; o.rho = prm->rho > 0 ? prm->rho : 1e4; o.feas_tol = prm->feas_tol > 0 ? prm->feas_tol : 1e-6;
         o.max_iter_free = prm->max_iter_free > 0 ? prm->max_iter_free : 3000; o.max_iter_fixed = prm->max_iter_fixed > 0 ? prm->max_iter_fixed : 1000;
+        o.max_soc = prm->max_soc == 0 ? 4 : (prm->max_soc < 0 ? 0 : prm->max_soc);
         status[q] = solve_one(&p, &o, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL);
         if (status[q] == ST_INFEASIBLE && p.variant == 4) {
             /* one penalty escalation for the free-time problem (see oracle/ipm_dense.py:solve): cold start again, rho x 100 */

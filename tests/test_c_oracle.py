@@ -26,7 +26,7 @@ def run_c(case):
 def test_c_follows_numpy_spec(nlp_golden, name):
     case = [c for c in nlp_golden if c["name"] == name][0]
     o = run_c(case)
-    r = ipm_dense.solve(build(case), {"max_soc": 0})
+    r = ipm_dense.solve(build(case))
     assert int(o["status"][0]) == r.status
     assert int(o["iters"][0]) == r.iters and int(o["info"][0, 3]) == r.nfact      # same iterate sequence
     np.testing.assert_allclose(o["xopt"][0], r.xopt, rtol=0, atol=1e-10)

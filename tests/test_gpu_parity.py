@@ -49,7 +49,7 @@ TIGHT = ["demo1_N6_mpc4_step0", "demo9_N5_mpc4_step0", "demo8_N5_mpc4_step0", "s
 def test_golden_scenarios_match_oracle(nlp_golden, solver_cls, name):
     case = [c for c in nlp_golden if c["name"] == name][0]
     x, u, feas, ts = getattr(solver_cls(), "obca_mpc%d" % case["variant"])(*ref_args(case))
-    r = ipm_dense.solve(build(case), {"max_soc": 0})
+    r = ipm_dense.solve(build(case))
     assert feas and r.feas
     assert x.shape == (3, case["inputs"]["N"] + 1) and u.shape == (2, case["inputs"]["N"])
     np.testing.assert_allclose(x, r.xopt, rtol=0, atol=1e-9)
@@ -83,7 +83,7 @@ def test_hard_fixed_time_cases_are_certified(nlp_golden, solver_cls, name):
     case = [c for c in nlp_golden if c["name"] == name][0]
     p = build(case)
     x, u, feas, ts = getattr(solver_cls(), "obca_mpc%d" % case["variant"])(*ref_args(case))
-    r = ipm_dense.solve(p, {"max_soc": 0})
+    r = ipm_dense.solve(p)
     assert feas == r.feas
     if feas:
         # primal feasibility of the kernel's trajectory in the ORIGINAL NLP (dynamics + bounds on x,u)
@@ -143,7 +143,7 @@ def test_batch_matches_oracle_and_is_permutation_invariant():
         p = Problem(4, N, b["m"], b["x0"][i], b["u0"][i], b["xref"][i], b["A"][i], b["b"][i], sc.TS,
                     0.1 * np.eye(3), 0.01 * np.eye(2), 0.1 * np.eye(2), 0.1 * np.eye(3), sc.XL, sc.XU,
                     [-0.6, -np.pi / 6], [0.6, np.pi / 6], sc.EGO, sc.DMIN)
-        r = ipm_dense.solve(p, {"max_soc": 0})
+        r = ipm_dense.solve(p)
         np.testing.assert_allclose(xo[i], r.xopt, rtol=0, atol=1e-5)
 
 

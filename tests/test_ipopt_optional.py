@@ -47,7 +47,7 @@ def test_unavailability_is_reported():
 def test_oracle_ipm_against_ipopt(nlp_golden, name):
     p = build([c for c in nlp_golden if c["name"] == name][0])
     ref = casadi_ipopt.solve(p)
-    r = ipm_dense.solve(p, {"max_soc": 0})
+    r = ipm_dense.solve(p)
     _compare(p, r.xopt, r.uopt, float(r.Ts_opt), bool(r.feas), ref)
 
 

@@ -27,7 +27,7 @@ def by_name(golden, name):
 @pytest.mark.parametrize("name", sorted(KNOWN))
 def test_known_answers(nlp_golden, name):
     p = build(by_name(nlp_golden, name))
-    r = ipm_dense.solve(p, {"max_soc": 0})
+    r = ipm_dense.solve(p)
     k = KNOWN[name]
     assert r.status == ipm_dense.STATUS_OK and r.feas
     assert r.Ts_opt == pytest.approx(k["T"] * p.Ts, abs=2e-6)
@@ -41,7 +41,7 @@ def test_known_answers(nlp_golden, name):
 
 def test_demo8_analytic_trajectory(nlp_golden):
     p = build(by_name(nlp_golden, "demo8_N5_mpc4_step0"))
-    r = ipm_dense.solve(p, {"max_soc": 0})
+    r = ipm_dense.solve(p)
     exp = np.array([[3 + 1.2 * k for k in range(6)], [4.0] * 6, [0.0] * 6])
     np.testing.assert_allclose(r.xopt, exp, atol=1e-6)
 
@@ -49,7 +49,7 @@ def test_demo8_analytic_trajectory(nlp_golden):
 def test_demo1_N5_is_infeasible(nlp_golden):
     """terminal reference pose (9,5,pi/4) puts the obstacle corner inside the footprint"""
     p = build(by_name(nlp_golden, "demo1_N5_mpc4_step0"))
-    r = ipm_dense.solve(p, {"max_soc": 0})
+    r = ipm_dense.solve(p)
     assert r.status == ipm_dense.STATUS_INFEASIBLE and not r.feas
     assert 1e-3 < r.elastic < 0.1
 
@@ -57,7 +57,7 @@ def test_demo1_N5_is_infeasible(nlp_golden):
 @pytest.mark.parametrize("name", ["demo1_dyn_mpc8", "slanted_asym_mpc6", "slanted_asym_mpc8", "slanted_asym_mpc4"])
 def test_fixed_time_and_slanted_certificates(nlp_golden, name):
     p = build(by_name(nlp_golden, name))
-    r = ipm_dense.solve(p, {"max_soc": 0})
+    r = ipm_dense.solve(p)
     assert r.feas
     cert = ipm_dense.kkt_certificate(p, r)
     assert cert["primal"] < 1e-7 and cert["stationarity"] < 1e-5 and cert["complementarity"] < 1e-5

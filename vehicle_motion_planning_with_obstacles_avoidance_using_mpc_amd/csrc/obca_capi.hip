@@ -29,6 +29,7 @@ struct obca_handle {
     const int32_t* warm_use;
     double warm_mu;
     double *cert_z, *cert_y;  /* obca_set_certificate_buffers */
+    double* soc_ws;           /* scratch of the second-order correction (wave kernels), max_batch x soc_stride doubles */
     double* ws;               /* lane kernel workspace, allocated on first use */
     size_t ws_stride;
     int* d_offm;
@@ -125,6 +126,11 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     h->prof = nullptr;
     h->warm_z = nullptr; h->warm_use = nullptr; h->warm_mu = 0.0;
     h->cert_z = nullptr; h->cert_y = nullptr;
+    h->soc_ws = nullptr;
+    if (h->wave_ok || h->mw_ok) {
+        const size_t stride = (size_t)h->n_max + 2 * (size_t)h->R_max + 2 * (size_t)(d->N + 1) * d->n_obs;
+        if (hipMalloc(&h->soc_ws, sizeof(double) * stride * (size_t)d->max_batch) != hipSuccess) { h->soc_ws = nullptr; delete h; return OBCA_E_NOMEM; }
+    }
     *out = h;
     return OBCA_OK;
 }
@@ -132,6 +138,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
 extern "C" void obca_destroy(obca_handle* h) {
     if (!h) return;
     if (h->ws) (void)hipFree(h->ws);
+    if (h->soc_ws) (void)hipFree(h->soc_ws);
     if (h->d_offm) (void)hipFree(h->d_offm);
     delete h;
 }
@@ -192,6 +199,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info; L.prof = h->prof;
     L.warm_z = h->warm_z; L.warm_use = h->warm_use; L.warm_mu = h->warm_mu;
     L.cert_z = h->cert_z; L.cert_y = h->cert_y;
+    L.soc_ws = h->soc_ws;
     auto cpw = [](ObcaWeightsDev& d, const obca_weights& s) {
         // the reference's double loops use Q[i,j] for every (i,j): only the symmetric part matters
         for (int a = 0; a < 3; ++a)
@@ -217,6 +225,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     L.prm.opt.feas_tol = p->feas_tol > 0 ? p->feas_tol : 1e-6;
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
+    L.prm.opt.max_soc = p->max_soc == 0 ? OBCA_MAX_SOC : (p->max_soc < 0 ? 0 : p->max_soc);
     if (lds_bytes) *lds_bytes = h->lds_bytes;
     if (wave_ok) *wave_ok = h->wave_ok ? 1 : 0;
     return OBCA_OK;

@@ -38,12 +38,14 @@
 #define OBCA_KAPPA_W_MINUS (1.0 / 3.0)
 #define OBCA_MAX_GRADIENT 100.0
 #define OBCA_ACCEPTABLE_ITER 15
+#define OBCA_KAPPA_SOC 0.99
+#define OBCA_MAX_SOC 4
 #define OBCA_RHO_ESCALATION 100.0   /* obca_mpc4 only: one retry with rho x 100 when elastic variables remain */
 
 #define OBCA_INST_DOUBLES 64   /* LDS reserved for the per-instance constant block (struct Inst) */
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
-struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed; };
+struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc; };
 struct ObcaParamsDev {
     ObcaWeightsDev free_time, fixed_time;
     double xL[2], xU[2], uL[2], uU[2];
@@ -65,6 +67,8 @@ struct ObcaLaunch {
     double warm_mu;        /* barrier parameter a warm-started solve begins with                                 */
     double* cert_z;        /* [B,n_max] final primal vector, or NULL: obca_set_certificate_buffers                        */
     double* cert_y;        /* [B,R_max + 2 npair] final multipliers (objective units), rows then rotation equalities, or NULL */
+    double* soc_ws;        /* [B, n_max + 2 R_max + 2 npair] scratch of the second-order correction (original direction, corrected
+                              residuals); NULL switches the correction off (wave kernels; the lane kernel keeps it in its workspace) */
     ObcaParamsDev prm;
 };
 

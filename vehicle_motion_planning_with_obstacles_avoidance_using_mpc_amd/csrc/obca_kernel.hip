@@ -1200,7 +1200,7 @@ struct ObcaHead {
     double *info, *prof, *warm_z;
     const int32_t* warm_use;
     double warm_mu;
-    double *cert_z, *cert_y;
+    double *cert_z, *cert_y, *soc_ws;
 };
 
 typedef const __attribute__((address_space(4))) ObcaLaunch ObcaLaunchConst;   // descriptor in HBM, read through the scalar cache
@@ -1218,7 +1218,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         A.b = uni<U>(Ain.b); A.Ts = uni<U>(Ain.Ts); A.term = uni<U>(Ain.term); A.xopt = uni<U>(Ain.xopt); A.uopt = uni<U>(Ain.uopt);
         A.ts_opt = uni<U>(Ain.ts_opt); A.status = uni<U>(Ain.status); A.iters = uni<U>(Ain.iters); A.info = uni<U>(Ain.info);
         A.prof = uni<U>(Ain.prof); A.warm_z = uni<U>(Ain.warm_z); A.warm_use = uni<U>(Ain.warm_use); A.warm_mu = uni<U>(Ain.warm_mu);
-        A.cert_z = uni<U>(Ain.cert_z); A.cert_y = uni<U>(Ain.cert_y);
+        A.cert_z = uni<U>(Ain.cert_z); A.cert_y = uni<U>(Ain.cert_y); A.soc_ws = uni<U>(Ain.soc_ws);
     }
     if (inst >= A.B) return;
     if (A.variant[inst] == 0) {                      // masked out by the caller (device-side closed loop)
@@ -1488,14 +1488,33 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             }
         }
         PROF(1)
-        // ---- Newton step with inertia correction -----------------------------------------------------------
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {       // unconditional writes end the live ranges of last iteration's step data,
-            W.dy[j] = 0.0; W.iDs[j] = 0.0; W.iDp[j] = 0.0; W.iDn[j] = 0.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
-        }                                      // so they do not occupy registers across the factorisation
+        // ---- Newton step with inertia correction, backtracking filter line search with second-order correction ------
+        // One copy of the solve pipeline serves the regular step (inertia loop) and IPOPT's second-order correction
+        // (max_soc = 4, kappa_soc = 0.99): when the FIRST trial step is rejected without reducing the constraint
+        // violation, up to max_soc corrected steps are tried -- same matrix (same delta_w), right-hand side from the
+        // accumulated residuals c_soc (rotation rows, kept in S.crot) and g_soc (rows, HBM scratch) -- before the step length
+        // is halved.  While a corrected direction is tried (use_soc) it sits in S.dx / W.dy / S.dnu and the original one
+        // waits in the HBM scratch A.soc_ws (rare path: ~1 line search in 2000 on the C2 workload).
+        double* const ws_dxo = A.soc_ws ? A.soc_ws + (size_t)inst * (A.n_max + 2 * A.R_max + 2 * L.npair) : nullptr;
+        double* const ws_dyo = ws_dxo + A.n_max;
+        double* const ws_gsoc = ws_dyo + A.R_max;
+        double* const ws_dnuo = ws_gsoc + A.R_max;
+        const int max_soc = A.soc_ws ? O.max_soc : 0;
         double delta_w = 0.0;
         bool first_try = true;
         int fail = 0;
+        double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0, alpha_min = 0.0, pw_th = 0.0, pw_dphi = 1.0;
+        double alpha = 1.0, a_try = 1.0, f_t = f, th_old = 0.0;
+        bool accepted = false, aug = false, first_trial = true, use_soc = false, soc_solve = false;
+        int soc_it = 0;
+        for (;;) {                                 // solve (regular or corrected), then line search; a correction comes back here
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {       // unconditional writes end the live ranges of the last step data,
+            W.dy[j] = 0.0; W.iDs[j] = 0.0; W.iDp[j] = 0.0; W.iDn[j] = 0.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
+        }                                      // so they do not occupy registers across the factorisation
+        if (soc_solve) {
+            (void)eval_objective<true>(L, S, in, S.x, sf, lane);   // the trial evaluation left ITS gradient in gf
+        }
         for (;;) {
 #pragma unroll
             for (int j = 0; j < RPL; ++j) {
@@ -1506,7 +1525,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                     const double lo_ = S.Lb[r], up_ = S.Ub[r];
                     const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], y, W.zL[j], W.zU[j], W.zp[j],
                                           W.zn[j], mu, rho, delta_w);
-                    const double rg = W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j];
+                    const double rg = soc_solve ? ws_gsoc[r] : W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j];
                     const double gh = rg + q.rs * q.iDs + q.rp * q.iDp - q.rn * q.iDn;
                     const double Ei = 1.0 / (q.iDs + q.iDp + q.iDn);
                     S.Einv[r] = Ei;
@@ -1528,7 +1547,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
 #endif
             PROF(5)
             ++nfact;
-            if (!bad) break;
+            if (!bad || soc_solve) break;          // a corrected solve reuses the accepted delta_w: same matrix, same pivots
             if (first_try) {
                 delta_w = (delta_w_last == 0.0) ? OBCA_DELTA_W_0 : fmax(OBCA_DELTA_W_MIN, OBCA_KAPPA_W_MINUS * delta_w_last);
                 first_try = false;
@@ -1537,10 +1556,11 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             }
             if (delta_w > OBCA_DELTA_W_MAX) { fail = 1; break; }
         }
-        if (fail) { status = OBCA_STATUS_NUMERIC; break; }
-        if (delta_w > 0.0) delta_w_last = delta_w;
-        // ---- row steps, step lengths, directional derivative -----------------------------------------------
-        double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0;
+        if (fail) break;
+        if (!soc_solve && delta_w > 0.0) delta_w_last = delta_w;
+        // ---- row steps, step lengths, directional derivative (the corrected solve only needs its own primal step length)
+        {
+        double am = 1.0, az = 1.0, dph = 0.0, ph = 0.0;
         for (int r = lane; r < L.R; r += NT)
             S.tmp[r] = row_soft(L, r) ? S.dy[r] : (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r];
 #pragma unroll
@@ -1565,44 +1585,51 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 double gs = eq ? 0.0 : W.rs[j] + W.y[j];
                 if (hasL) {
                     const double sl = s - lo_, zL = W.zL[j];
-                    if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
+                    if (ds < 0.0) am = fmin(am, -tau * sl / ds);
                     const double dz = (mu - zL * ds) / sl - zL;
-                    if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
+                    if (dz < 0.0) az = fmin(az, -tau * zL / dz);
                 }
                 if (hasU) {
                     const double su = up_ - s, zU = W.zU[j];
-                    if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
+                    if (ds > 0.0) am = fmin(am, tau * su / ds);
                     const double dz = (mu + zU * ds) / su - zU;
-                    if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
+                    if (dz < 0.0) az = fmin(az, -tau * zU / dz);
                 }
-                if (dp < 0.0) a_max = fmin(a_max, -tau * p / dp);
-                if (dn < 0.0) a_max = fmin(a_max, -tau * n / dn);
+                if (dp < 0.0) am = fmin(am, -tau * p / dp);
+                if (dn < 0.0) am = fmin(am, -tau * n / dn);
                 const double zp = W.zp[j], zn = W.zn[j];
                 const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
-                if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
-                if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
-                phi += w * row_barrier(lo_, up_, eq, s, p, n, mu, rho);
-                dphi += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
+                if (dzp < 0.0) az = fmin(az, -tau * zp / dzp);
+                if (dzn < 0.0) az = fmin(az, -tau * zn / dzn);
+                if (!soc_solve) {
+                    ph += w * row_barrier(lo_, up_, eq, s, p, n, mu, rho);
+                    dph += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
+                }
             }
         }
-        for (int t = lane; t < L.n; t += NT) dphi += S.gf[t] * S.dx[t];
-        a_max = red_min(a_max); a_z = red_min(a_z); dphi = red_sum(dphi); phi = red_sum(phi) + f;
-        double alpha_min;
-        // the two powers of the switching condition do not depend on the step length: once per iteration, not per trial
-        double pw_th = 0.0, pw_dphi = 1.0;
-        if (dphi < 0.0) {
-            pw_th = dpow(th, OBCA_S_THETA);
-            pw_dphi = dpow(-dphi, OBCA_S_PHI);
-            double c = fmin(OBCA_GAMMA_THETA, OBCA_GAMMA_PHI * th / (-dphi));
-            if (th <= theta_min) c = fmin(c, OBCA_DELTA * pw_th / pw_dphi);
-            alpha_min = OBCA_GAMMA_ALPHA * c;
-        } else alpha_min = OBCA_GAMMA_ALPHA * OBCA_GAMMA_THETA;
+        am = red_min(am);
+        if (soc_solve) {
+            a_try = am;                            // fraction-to-boundary step of the corrected direction
+        } else {
+            for (int t = lane; t < L.n; t += NT) dph += S.gf[t] * S.dx[t];
+            a_max = am; a_z = red_min(az); dphi = red_sum(dph); phi = red_sum(ph) + f;
+            // the two powers of the switching condition do not depend on the step length: once per iteration, not per trial
+            pw_th = 0.0; pw_dphi = 1.0;
+            if (dphi < 0.0) {
+                pw_th = dpow(th, OBCA_S_THETA);
+                pw_dphi = dpow(-dphi, OBCA_S_PHI);
+                double c = fmin(OBCA_GAMMA_THETA, OBCA_GAMMA_PHI * th / (-dphi));
+                if (th <= theta_min) c = fmin(c, OBCA_DELTA * pw_th / pw_dphi);
+                alpha_min = OBCA_GAMMA_ALPHA * c;
+            } else alpha_min = OBCA_GAMMA_ALPHA * OBCA_GAMMA_THETA;
+            alpha = a_max; a_try = a_max;
+        }
+        }
         PROF(6)
         // ---- backtracking filter line search ---------------------------------------------------------------
-        double alpha = a_max, f_t = f;
-        bool accepted = false, aug = false;
+        soc_solve = false;
         for (;;) {
-            for (int t = lane; t < L.n; t += NT) S.xt[t] = S.x[t] + alpha * S.dx[t];
+            for (int t = lane; t < L.n; t += NT) S.xt[t] = S.x[t] + a_try * S.dx[t];
             SYNC();
             eval_geom(L, S, S.xt, S.ctt, S.stt, S.cct, lane);
             f_t = eval_objective<true>(L, S, in, S.xt, sf, lane);     // gradient too: gf of the current point is spent
@@ -1615,9 +1642,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                     const bool eq = row_iseq(L, r);
                     const double dy = W.dy[j], w = row_w(L, r);
                     const double lo_ = S.Lb[r], up_ = S.Ub[r];
-                    const double st = eq ? 0.0 : W.s[j] + alpha * (dy - W.rs[j]) * W.iDs[j];
-                    const double pt = W.p[j] + alpha * (dy - W.rp[j]) * W.iDp[j];
-                    const double nt = W.n[j] + alpha * (-dy - W.rn[j]) * W.iDn[j];
+                    const double st = eq ? 0.0 : W.s[j] + a_try * (dy - W.rs[j]) * W.iDs[j];
+                    const double pt = W.p[j] + a_try * (dy - W.rp[j]) * W.iDp[j];
+                    const double nt = W.n[j] + a_try * (-dy - W.rn[j]) * W.iDn[j];
                     const double gt = S.tmp[r];
                     th_t += w * fabs(gt - st - pt + nt);
                     phi_t += w * row_barrier(lo_, up_, eq, st, pt, nt, mu, rho);
@@ -1627,8 +1654,8 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 double e1, e2;
                 rot_value(L, S.xt, S.ctt, S.stt, S.cct, pr, e1, e2);
                 th_t += fabs(e1) + fabs(e2);
-                S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;      // the current point's values are not needed any more;
-            }                                                      // the accepted trial's are the next iterate's
+                S.bx[2 * pr] = e1; S.bx[2 * pr + 1] = e2;          // bx is free during the line search: the trial's
+            }                                                      // rotation residuals (the accepted ones become crot)
             th_t = red_sum(th_t);
             phi_t = red_sum(phi_t) + f_t;
             bool ok = false;
@@ -1649,9 +1676,62 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 }
             }
             if (ok) { accepted = true; break; }
+            // ---- second-order correction bookkeeping (rare)
+            const bool fin_eval = isfinite(th_t) && isfinite(f_t);
+            bool soc_start = false, soc_next = false;
+            if (use_soc) {
+                if (!fin_eval || th_t > OBCA_KAPPA_SOC * th_old || soc_it >= max_soc) {
+                    for (int t = lane; t < L.n; t += NT) S.dx[t] = ws_dxo[t];           // back to the original direction
+                    for (int t = lane; t < 2 * L.npair; t += NT) S.dnu[t] = ws_dnuo[t];
+#pragma unroll
+                    for (int j = 0; j < RPL; ++j) {
+                        const int r = lane + NT * j;
+                        if (r < L.R) W.dy[j] = ws_dyo[r];
+                    }
+                    use_soc = false;
+                    SYNC();
+                } else soc_next = true;
+            } else if (first_trial && max_soc > 0 && fin_eval && th_t >= th) {
+                soc_start = true;
+            }
+            first_trial = false;
+            if (soc_start || soc_next) {
+                const double cf = soc_start ? alpha : a_try;
+#pragma unroll
+                for (int j = 0; j < RPL; ++j) {
+                    const int r = lane + NT * j;
+                    if (r < L.R) {
+                        const bool eq = row_iseq(L, r);
+                        const double dy = W.dy[j];
+                        const double st = eq ? 0.0 : W.s[j] + a_try * (dy - W.rs[j]) * W.iDs[j];
+                        const double pt = W.p[j] + a_try * (dy - W.rp[j]) * W.iDp[j];
+                        const double nt = W.n[j] + a_try * (-dy - W.rn[j]) * W.iDn[j];
+                        const double res = S.tmp[r] - st - pt + nt;
+                        const double old = soc_start ? W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j] : ws_gsoc[r];
+                        ws_gsoc[r] = cf * old + res;
+                        if (soc_start) ws_dyo[r] = dy;
+                    }
+                }
+                if (soc_start) {
+                    for (int t = lane; t < L.n; t += NT) ws_dxo[t] = S.dx[t];
+                    for (int t = lane; t < 2 * L.npair; t += NT) ws_dnuo[t] = S.dnu[t];
+                }
+                for (int t = lane; t < 2 * L.npair; t += NT) S.crot[t] = cf * S.crot[t] + S.bx[t];
+                th_old = th_t;
+                use_soc = true;
+                soc_solve = true;
+                ++soc_it;
+                __threadfence_block();
+                SYNC();
+                break;                              // to the solve with the corrected right-hand side
+            }
             alpha *= 0.5;
+            a_try = alpha;
             if (alpha < alpha_min) break;
         }
+        if (!soc_solve) break;
+        }
+        if (fail) { status = OBCA_STATUS_NUMERIC; break; }
         PROF(7)
         if (!accepted) { status = OBCA_STATUS_LINESEARCH; break; }
         if (aug) {
@@ -1673,6 +1753,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
 #endif
         }
         // ---- accept ------------------------------------------------------------------------------------------
+        // bound multipliers follow the ORIGINAL direction (step a_z); primal variables, y and nu the accepted one
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
             const int r = lane + NT * j;
@@ -1681,33 +1762,37 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const double lo_ = S.Lb[r], up_ = S.Ub[r];
             const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
                 const double dy = W.dy[j];
+                const double dyz = use_soc ? ws_dyo[r] : dy;
                 const double ds = (dy - W.rs[j]) * W.iDs[j];
                 const double dp = (dy - W.rp[j]) * W.iDp[j];
                 const double dn = (-dy - W.rn[j]) * W.iDn[j];
+                const double dsz = (dyz - W.rs[j]) * W.iDs[j];
+                const double dpz = (dyz - W.rp[j]) * W.iDp[j];
+                const double dnz = (-dyz - W.rn[j]) * W.iDn[j];
                 const double lo = lo_, up = up_;
                 const double s_old = W.s[j], p_old = W.p[j], n_old = W.n[j];
-                const double s = eq ? 0.0 : s_old + alpha * ds, p = p_old + alpha * dp, n = n_old + alpha * dn;
+                const double s = eq ? 0.0 : s_old + a_try * ds, p = p_old + a_try * dp, n = n_old + a_try * dn;
                 const double ks = OBCA_KAPPA_SIGMA;
                 if (hasL) {
-                    const double zL = W.zL[j] + a_z * ((mu - W.zL[j] * ds) / (s_old - lo) - W.zL[j]);
+                    const double zL = W.zL[j] + a_z * ((mu - W.zL[j] * dsz) / (s_old - lo) - W.zL[j]);
                     const double sl = s - lo;
                     W.zL[j] = fmax(fmin(zL, ks * mu / sl), mu / (ks * sl));
                 }
                 if (hasU) {
-                    const double zU = W.zU[j] + a_z * ((mu + W.zU[j] * ds) / (up - s_old) - W.zU[j]);
+                    const double zU = W.zU[j] + a_z * ((mu + W.zU[j] * dsz) / (up - s_old) - W.zU[j]);
                     const double su = up - s;
                     W.zU[j] = fmax(fmin(zU, ks * mu / su), mu / (ks * su));
                 }
-                const double zp = W.zp[j] + a_z * ((mu - W.zp[j] * dp) / p_old - W.zp[j]);
-                const double zn = W.zn[j] + a_z * ((mu - W.zn[j] * dn) / n_old - W.zn[j]);
+                const double zp = W.zp[j] + a_z * ((mu - W.zp[j] * dpz) / p_old - W.zp[j]);
+                const double zn = W.zn[j] + a_z * ((mu - W.zn[j] * dnz) / n_old - W.zn[j]);
                 W.zp[j] = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
                 W.zn[j] = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
                 W.s[j] = s; W.p[j] = p; W.n[j] = n;
-                W.y[j] += alpha * dy;
+                W.y[j] += a_try * dy;
                 S.y[r] = W.y[j];
             }
         }
-        for (int t = lane; t < 2 * L.npair; t += NT) S.nu[t] += alpha * S.dnu[t];
+        for (int t = lane; t < 2 * L.npair; t += NT) { S.nu[t] += a_try * S.dnu[t]; S.crot[t] = S.bx[t]; }
         for (int t = lane; t < L.n; t += NT) S.x[t] = S.xt[t];
         SYNC();
         fobj_prev = fobj;

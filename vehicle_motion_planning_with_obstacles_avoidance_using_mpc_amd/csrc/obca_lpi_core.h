@@ -71,6 +71,7 @@ struct Sh {
     SP Lall, lall, Y;
     SP Pk, qk, Kk, kapk, Mik;
     SP filt;
+    SP gsoc, rest, dyo, dxo, dnuo, crot_t;    // second-order correction: corrected residuals, trial residuals, saved original direction
     const int* offm;
 };
 
@@ -80,7 +81,7 @@ LPI_FN void lpi_sincos(double x, double* s, double* c) { *s = sin(x); *c = cos(x
 // number of workspace doubles per instance and the carve-up (host and device use the same function)
 struct Carve {
     int x, xt, dx, gf, bx, y, Einv, yhat, gh, dy, s, p, n, zL, zU, zp, zn, g, ct, st, cc, ctt, stt, cct, nu, dnu, crot,
-        Aobs, bobs, xref, Lall, lall, Y, Pk, qk, Kk, kapk, Mik, filt, total;
+        Aobs, bobs, xref, Lall, lall, Y, Pk, qk, Kk, kapk, Mik, filt, gsoc, rest, dyo, dxo, dnuo, crot_t, total;
 };
 LPI_HD Carve carve(int N, int nO, int M, int n_max, int R_max) {
     Carve c;
@@ -96,6 +97,7 @@ LPI_HD Carve carve(int N, int nO, int M, int n_max, int R_max) {
     TK(Lall, 64 * N1) TK(lall, 8 * N1) TK(Y, MW * 4 * np)
     TK(Pk, 36 * N1) TK(qk, 6 * N1) TK(Kk, 12 * N1) TK(kapk, 2 * N1) TK(Mik, 9 * (N1 + 1))
     TK(filt, 2 * FILT_MAX)
+    TK(gsoc, R_max) TK(rest, R_max) TK(dyo, R_max) TK(dxo, n_max) TK(dnuo, 2 * np) TK(crot_t, 2 * np)
 #undef TK
     c.total = t;
     return c;
@@ -1174,10 +1176,16 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
             if (th <= theta_min) c = fmin(c, OBCA_DELTA * pow(th, OBCA_S_THETA) / pow(-dphi, OBCA_S_PHI));
             alpha_min = OBCA_GAMMA_ALPHA * c;
         } else alpha_min = OBCA_GAMMA_ALPHA * OBCA_GAMMA_THETA;
-        double alpha = a_max, f_t = f;
-        bool accepted = false, aug = false;
+        // backtracking filter line search with IPOPT's second-order correction: when the FIRST trial step is rejected and
+        // did not reduce the constraint violation, up to max_soc corrected steps are tried (same matrix, i.e. the same
+        // delta_w; right-hand side from the accumulated residuals c_soc / g_soc; own fraction-to-boundary step a_soc;
+        // acceptance tested with the ORIGINAL alpha) before the step length is halved.  a_try / S.dx / S.dy hold the
+        // direction being tried -- the corrected one while use_soc -- and the original one waits in dxo / dyo / dnuo.
+        double alpha = a_max, a_try = a_max, f_t = f, th_old = 0.0;
+        bool accepted = false, aug = false, first_trial = true, use_soc = false;
+        int soc_it = 0;
         for (;;) {
-            for (int t = 0; t < L.n; ++t) S.xt[t] = S.x[t] + alpha * S.dx[t];
+            for (int t = 0; t < L.n; ++t) S.xt[t] = S.x[t] + a_try * S.dx[t];
             eval_geom(L, S, S.xt, S.ctt, S.stt, S.cct, 0);
             f_t = eval_objective<false>(L, S, in, S.xt, sf, 0);
             double th_t = 0.0, phi_t = f_t;
@@ -1188,20 +1196,24 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
                 const double dy = S.dy[r], w = row_w(L, r);
                 const double s = S.s[r], p = S.p[r], n = S.n[r];
                 const Lin q = row_lin(lo, up, eq, s, p, n, S.y[r], S.zL[r], S.zU[r], S.zp[r], S.zn[r], mu, rho, delta_w);
-                const double st = eq ? 0.0 : s + alpha * (dy - q.rs) * q.iDs;
-                const double pt = p + alpha * (dy - q.rp) * q.iDp;
-                const double nt = n + alpha * (-dy - q.rn) * q.iDn;
+                const double st = eq ? 0.0 : s + a_try * (dy - q.rs) * q.iDs;
+                const double pt = p + a_try * (dy - q.rp) * q.iDp;
+                const double nt = n + a_try * (-dy - q.rn) * q.iDn;
                 const double gt = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
-                th_t += w * fabs(gt - st - pt + nt);
+                const double res = gt - st - pt + nt;
+                S.rest[r] = res;
+                th_t += w * fabs(res);
                 phi_t += w * row_barrier_lpi(lo, up, eq, st, pt, nt, mu, rho);
             }
             for (int pr = 0; pr < L.npair; ++pr) {
                 double e1, e2;
                 rot_value(L, S.xt, S.ctt, S.stt, S.cct, pr, e1, e2);
                 th_t += fabs(e1) + fabs(e2);
+                S.crot_t[2 * pr] = e1; S.crot_t[2 * pr + 1] = e2;
             }
             bool ok = false;
             aug = false;
+            const bool finite = isfinite(th_t) && isfinite(f_t);
             bool blocked = !(th_t < theta_max) || !isfinite(phi_t);
             for (int i = 0; i < nfilt && !blocked; ++i)
                 if (th_t >= S.filt[2 * i] && phi_t >= S.filt[2 * i + 1]) blocked = true;
@@ -1215,11 +1227,72 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
                 }
             }
             if (ok) { accepted = true; break; }
+            bool solve_soc = false;
+            if (use_soc) {
+                if (!finite || th_t > OBCA_KAPPA_SOC * th_old || soc_it >= O.max_soc) {
+                    for (int t = 0; t < L.n; ++t) S.dx[t] = S.dxo[t];          // back to the original direction
+                    for (int t = 0; t < 2 * L.npair; ++t) S.dnu[t] = S.dnuo[t];
+                    for (int r = 0; r < L.R; ++r) S.dy[r] = S.dyo[r];
+                    use_soc = false;
+                } else {
+                    th_old = th_t;
+                    for (int t = 0; t < 2 * L.npair; ++t) S.crot[t] = a_try * S.crot[t] + S.crot_t[t];
+                    for (int r = 0; r < L.R; ++r) S.gsoc[r] = a_try * S.gsoc[r] + S.rest[r];
+                    solve_soc = true;
+                }
+            } else if (first_trial && O.max_soc > 0 && finite && th_t >= th) {
+                for (int t = 0; t < L.n; ++t) S.dxo[t] = S.dx[t];
+                for (int t = 0; t < 2 * L.npair; ++t) { S.dnuo[t] = S.dnu[t]; S.crot[t] = alpha * S.crot[t] + S.crot_t[t]; }
+                for (int r = 0; r < L.R; ++r) {
+                    S.dyo[r] = S.dy[r];
+                    S.gsoc[r] = alpha * (S.g[r] - (row_iseq(L, r) ? 0.0 : S.s[r]) - S.p[r] + S.n[r]) + S.rest[r];
+                }
+                th_old = th_t;
+                use_soc = true;
+                solve_soc = true;
+            }
+            first_trial = false;
+            if (solve_soc) {
+                ++soc_it;
+                for (int r = 0; r < L.R; ++r) {
+                    const bool eq = row_iseq(L, r);
+                    double lo, up;
+                    row_bounds(L, in, r, lo, up);
+                    const double y = S.y[r];
+                    const Lin q = row_lin(lo, up, eq, S.s[r], S.p[r], S.n[r], y, S.zL[r], S.zU[r], S.zp[r], S.zn[r], mu, rho, delta_w);
+                    const double gh = S.gsoc[r] + q.rs * q.iDs + q.rp * q.iDp - q.rn * q.iDn;
+                    S.gh[r] = gh;
+                    S.yhat[r] = row_soft(L, r) ? y : (y + gh * S.Einv[r]);
+                }
+                gather_grad(L, S, in, S.yhat, S.bx, 0);
+                assemble_stages(L, S, in, sf, delta_w, 0);
+                (void)local_blocks(L, S, in, delta_w);            // same matrix as the accepted factorisation: same pivots
+                (void)riccati(L, S, in);
+                ++o.nfact;
+                a_try = 1.0;
+                for (int r = 0; r < L.R; ++r) {
+                    const bool eq = row_iseq(L, r);
+                    double lo, up;
+                    row_bounds(L, in, r, lo, up);
+                    const bool hasL = !eq && lo > -INFINITY, hasU = !eq && up < INFINITY;
+                    const double dy = row_soft(L, r) ? S.dy[r] : (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r];
+                    S.dy[r] = dy;
+                    const double s = S.s[r], p = S.p[r], n = S.n[r];
+                    const Lin q = row_lin(lo, up, eq, s, p, n, S.y[r], S.zL[r], S.zU[r], S.zp[r], S.zn[r], mu, rho, delta_w);
+                    const double ds = (dy - q.rs) * q.iDs, dp = (dy - q.rp) * q.iDp, dn = (-dy - q.rn) * q.iDn;
+                    if (hasL && ds < 0.0) a_try = fmin(a_try, -tau * (s - lo) / ds);
+                    if (hasU && ds > 0.0) a_try = fmin(a_try, tau * (up - s) / ds);
+                    if (dp < 0.0) a_try = fmin(a_try, -tau * p / dp);
+                    if (dn < 0.0) a_try = fmin(a_try, -tau * n / dn);
+                }
+                continue;
+            }
             alpha *= 0.5;
+            a_try = alpha;
             if (alpha < alpha_min) break;
         }
         LPI_TRACE_LINE("it %3d th %.2e phi %.6e dphi %.2e mu %.1e dw %.1e a %.2e nfact %d nfilt %d\n", it, th, phi, dphi, mu,
-                       delta_w, accepted ? alpha : -1.0, o.nfact, nfilt);
+                       delta_w, accepted ? a_try : -1.0, o.nfact, nfilt);
         if (!accepted) { o.status = OBCA_STATUS_LINESEARCH; break; }
         if (aug) {
             const double tn = (1.0 - OBCA_GAMMA_THETA) * th, pn = phi - OBCA_GAMMA_PHI * th;
@@ -1237,29 +1310,31 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
             double lo, up;
             row_bounds(L, in, r, lo, up);
             const bool hasL = !eq && lo > -INFINITY, hasU = !eq && up < INFINITY;
-            const double dy = S.dy[r];
+            // bound multipliers follow the ORIGINAL direction (step a_z); primal variables and y the accepted one
+            const double dy = S.dy[r], dyz = use_soc ? S.dyo[r] : dy;
             const double s_old = S.s[r], p_old = S.p[r], n_old = S.n[r], y = S.y[r];
             const double zL0 = S.zL[r], zU0 = S.zU[r], zp0 = S.zp[r], zn0 = S.zn[r];
             const Lin q = row_lin(lo, up, eq, s_old, p_old, n_old, y, zL0, zU0, zp0, zn0, mu, rho, delta_w);
             const double ds = (dy - q.rs) * q.iDs, dp = (dy - q.rp) * q.iDp, dn = (-dy - q.rn) * q.iDn;
-            const double s = eq ? 0.0 : s_old + alpha * ds, p = p_old + alpha * dp, n = n_old + alpha * dn;
+            const double dsz = (dyz - q.rs) * q.iDs, dpz = (dyz - q.rp) * q.iDp, dnz = (-dyz - q.rn) * q.iDn;
+            const double s = eq ? 0.0 : s_old + a_try * ds, p = p_old + a_try * dp, n = n_old + a_try * dn;
             const double ks = OBCA_KAPPA_SIGMA;
             if (hasL) {
-                const double zL = zL0 + a_z * ((mu - zL0 * ds) / (s_old - lo) - zL0), sl = s - lo;
+                const double zL = zL0 + a_z * ((mu - zL0 * dsz) / (s_old - lo) - zL0), sl = s - lo;
                 S.zL[r] = fmax(fmin(zL, ks * mu / sl), mu / (ks * sl));
             }
             if (hasU) {
-                const double zU = zU0 + a_z * ((mu + zU0 * ds) / (up - s_old) - zU0), su = up - s;
+                const double zU = zU0 + a_z * ((mu + zU0 * dsz) / (up - s_old) - zU0), su = up - s;
                 S.zU[r] = fmax(fmin(zU, ks * mu / su), mu / (ks * su));
             }
-            const double zp = zp0 + a_z * ((mu - zp0 * dp) / p_old - zp0);
-            const double zn = zn0 + a_z * ((mu - zn0 * dn) / n_old - zn0);
+            const double zp = zp0 + a_z * ((mu - zp0 * dpz) / p_old - zp0);
+            const double zn = zn0 + a_z * ((mu - zn0 * dnz) / n_old - zn0);
             S.zp[r] = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
             S.zn[r] = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
             S.s[r] = s; S.p[r] = p; S.n[r] = n;
-            S.y[r] = y + alpha * dy;
+            S.y[r] = y + a_try * dy;
         }
-        for (int t = 0; t < 2 * L.npair; ++t) S.nu[t] += alpha * S.dnu[t];
+        for (int t = 0; t < 2 * L.npair; ++t) S.nu[t] += a_try * S.dnu[t];
         for (int t = 0; t < L.n; ++t) S.x[t] = S.xt[t];
         fobj_prev = fobj;
         have_prev = true;
@@ -1305,7 +1380,7 @@ LPI_FN void bind(Sh& S, const Carve& c, double* ws, size_t stride, size_t inst, 
 #define B(name) S.name = SP{ws + (size_t)c.name * stride + inst, stride};
     B(x) B(xt) B(dx) B(gf) B(bx) B(y) B(Einv) B(yhat) B(gh) B(dy) B(s) B(p) B(n) B(zL) B(zU) B(zp) B(zn) B(g)
     B(ct) B(st) B(cc) B(ctt) B(stt) B(cct) B(nu) B(dnu) B(crot) B(Aobs) B(bobs) B(xref) B(Lall) B(lall) B(Y)
-    B(Pk) B(qk) B(Kk) B(kapk) B(Mik) B(filt)
+    B(Pk) B(qk) B(Kk) B(kapk) B(Mik) B(filt) B(gsoc) B(rest) B(dyo) B(dxo) B(dnuo) B(crot_t)
 #undef B
     S.offm = offm;
 }
