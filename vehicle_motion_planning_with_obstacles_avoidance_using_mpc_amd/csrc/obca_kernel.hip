@@ -1315,7 +1315,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     SYNC();
 
     ObcaOptsDev O;
-    O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed;          // by value: A may live in HBM (fused closed-loop kernel); the descriptor of
+    O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed; O.max_soc = Ain.prm.opt.max_soc;          // by value: A may live in HBM (fused closed-loop kernel); the descriptor of
                                               // an escalated pass carries rho x 100 itself
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
