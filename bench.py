@@ -29,6 +29,41 @@ ALG_BYTES = {(5, 6): 1320, (5, 12): 2184, (6, 6): 1528}       # SURVEY.md 8(d): 
 HBM_PEAK_GBPS = 8000.0                                          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
 
 
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+
+
+def pmc_summary(kernel, B, N, M):
+    """HBM traffic and issue counters of the dominant kernel, from the rocprofv3 --pmc passes committed under profiles/
+    (tools/pmc_summary.py turns the counter CSVs into this file).  None when no pass matches this workload."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            rows = json.load(f)["kernels"]
+    except Exception:
+        return None
+    for r in rows:
+        if r.get("kernel") == kernel and (r.get("B"), r.get("N"), r.get("M")) == (B, N, M):
+            return r
+    return None
+
+
+def ipopt_leg(batch, N, seconds=10.0):
+    """the reference's own solver (CasADi/IPOPT) on the same instances, one core, when casadi imports."""
+    from oracle import casadi_ipopt
+    if not casadi_ipopt.available():
+        return "unavailable"
+    from oracle.obca_nlp import Problem
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    n, ok, t0 = 0, 0, time.time()
+    while time.time() - t0 < seconds and n < batch["x0"].shape[0]:
+        p = Problem(4, N, batch["m"], batch["x0"][n], batch["u0"][n], batch["xref"][n], batch["A"][n], batch["b"][n],
+                    sc.TS, 0.1 * np.eye(3), 0.01 * np.eye(2), 0.1 * np.eye(2), 0.1 * np.eye(3), sc.XL, sc.XU,
+                    [-0.6, -np.pi / 6], [0.6, np.pi / 6], sc.EGO, sc.DMIN)
+        ok += bool(casadi_ipopt.solve(p)["feas"])
+        n += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "MPC steps/s", "cores": 1, "solved": ok, "sample": "%d instances, CasADi Opti + IPOPT, %.1f s" % (n, dt)}
+
+
 def alg_bytes(N, M):
     return 8 * (3 + 2 + 3 * (N + 1) + 3 * M * (N + 1) + 1 + 3) + 8 * (3 * (N + 1) + 2 * N + 1) + 8
 
@@ -94,17 +129,16 @@ def cpu_structured(batch, N):
             "sample": "%d instances of the same batch, structured core on the host, %d OpenMP threads, %.1f s" % (n, cores, dt)}
 
 
-def config_c3(B, N=20, unique=256):
+def config_c3(B, N=20):
     """Config C3: N=20, walls + box + two moving boxes, lidar-gated: the free-time sub-batch (obca_mpc4, three
-    static obstacles) and the gated sub-batch (obca_mpc6, five obstacles, time-varying rows), B instances each (the
-    generator's first `unique` instances of each kind, repeated); both run on the four-wavefront LDS kernel."""
+    static obstacles) and the gated sub-batch (obca_mpc6, five obstacles, time-varying rows), B UNIQUE seeded instances
+    each; both run on the four-wavefront LDS kernel."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
-    res = {"workload": "C3 (SURVEY 8d): N=%d, B=%d per sub-batch, %d unique instances each" % (N, B, unique)}
+    res = {"workload": "C3 (SURVEY 8d): N=%d, B=%d unique seeded instances per sub-batch" % (N, B)}
+    procs = max(1, min(48, (os.cpu_count() or 1) // 2))
     for name, gated in (("free_time_obca_mpc4", False), ("gated_obca_mpc6", True)):
-        base = sc.make_batch_c3(unique, N, gated=gated)
-        rep = (B + unique - 1) // unique
-        b = {k: (np.concatenate([v] * rep)[:B] if isinstance(v, np.ndarray) else v) for k, v in base.items()}
+        b = sc.make_batch_c3(B, N, gated=gated, procs=procs)
         s = BatchSolver(N, b["m"], B)
         dv = {k: torch.as_tensor(b[k], device="cuda") for k in ("variant", "x0", "u0", "xref", "A", "b", "Ts", "term")}
         out = None
@@ -117,37 +151,58 @@ def config_c3(B, N=20, unique=256):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         ok = int(((out.status == 0) | (out.status == 1)).sum())
+        st = out.status.cpu().numpy()
         res[name] = {"value": ok / best, "unit": "converged solves/s", "ms_per_launch": best * 1e3, "success_rate": ok / B,
+                     "status_counts": {str(k): int((st == k).sum()) for k in np.unique(st)},
                      "mean_ipm_iters": float(out.iters.float().mean()), "lds_bytes": s.lds_bytes}
         s.close()
     return res
 
 
-def closed_loop_c5(B, n_dyn=2, warm_start=None):
-    """Config C5: B Monte-Carlo rollouts of the receding-horizon loop, harness and solves on the device
-    (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds resident in HBM before the clock starts."""
+def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None):
+    """Config C5: B Monte-Carlo rollouts of the receding-horizon loop per GPU, harness and solves on the device
+    (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds first .. first+B-1, resident in HBM
+    before the clock starts.  With a process group every rank runs the whole loop for its own worlds (no collective on
+    the data path); the time is the max over ranks, the steps are summed."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
-    w = pack_worlds([sc.make_world_c5(i, n_dyn=n_dyn) for i in range(B)])
+    w = pack_worlds([sc.make_world_c5(first + i, n_dyn=n_dyn) for i in range(B)])
     dr = DeviceRollouts(w, N=5, warm_start=warm_start)
     dr.run(1)
     torch.cuda.synchronize()
     dr.reset()
     torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     dr.run()
     torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
     dt = time.perf_counter() - t0
     o = {k: v.cpu().numpy() for k, v in dr.read().items()}
     ok, tried = int(o["steps"].sum()), int((o["variant"] > 0).sum())
-    return {"workload": "C5 (SURVEY 8d): %d closed-loop rollouts, N=5, walls + random box + %d moving 3x3 boxes (lidar gate 10 m), "
-                        "<=30 steps each, obca_mpc4 / obca_mpc6 -> obca_mpc8 as the reference dispatches them; harness and "
-                        "solves in one persistent kernel (obca_rollouts_run)" % (B, n_dyn),
-            "value": ok / dt, "unit": "converged closed-loop MPC steps/s", "seconds": dt, "converged_steps": ok,
-            "attempted_steps": tried, "rollouts_to_step_cap": int((o["flags"] == 2).sum()),
-            "rollouts_stopped_infeasible": int((o["flags"] == 3).sum()),
-            "solves_by_variant": {str(v): int((o["variant"] == v).sum()) for v in (4, 6, 8)},
-            "mean_ipm_iters": float(o["iters"][o["variant"] > 0].mean())}
+    world = 1
+    if dist:
+        world = dist.get_world_size()
+        acc = torch.tensor([float(ok), float(tried), float((o["flags"] == 2).sum()), float((o["flags"] == 3).sum())], device="cuda", dtype=torch.float64)
+        tm = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ok, tried, dt = int(acc[0]), int(acc[1]), float(tm[0])
+        caps, fails = int(acc[2]), int(acc[3])
+    else:
+        caps, fails = int((o["flags"] == 2).sum()), int((o["flags"] == 3).sum())
+    res = {"workload": "C5 (SURVEY 8d): %d closed-loop rollouts%s, N=5, walls + random box + %d moving 3x3 boxes (lidar gate 10 m), "
+                       "<=30 steps each, obca_mpc4 / obca_mpc6 -> obca_mpc8 as the reference dispatches them; harness and "
+                       "solves in one persistent kernel (obca_rollouts_run)" % (B * world, " (%d per GPU)" % B if world > 1 else "", n_dyn),
+           "value": ok / dt, "unit": "converged closed-loop MPC steps/s", "seconds": dt, "converged_steps": ok,
+           "attempted_steps": tried, "rollouts_to_step_cap": caps, "rollouts_stopped_infeasible": fails}
+    if world == 1:
+        res["solves_by_variant"] = {str(v): int((o["variant"] == v).sum()) for v in (4, 6, 8)}
+        res["mean_ipm_iters"] = float(o["iters"][o["variant"] > 0].mean())
+    return res
 
 
 def main():
@@ -190,6 +245,7 @@ def main():
     batch = sc.make_batch(B, N, three_boxes=args.three_boxes, first=rank * B)      # shard: instances rank*B ..
     M = sum(batch["m"])
     solver = BatchSolver(N, batch["m"], max_batch=B, device=dev)
+    solver_rows = 3 + 3 * N + 3 + 2 * (N + 1) + 4 * N + 2 + (N + 1) * (2 * len(batch["m"]) + M + 4 * len(batch["m"]))
     prm = SolverParams()
     dv = {k: torch.as_tensor(batch[k], device=dev) for k in ("variant", "x0", "u0", "xref", "A", "b", "Ts", "term")}
     torch.cuda.synchronize()
@@ -254,11 +310,20 @@ def main():
         assert full["xopt"].shape[0] == B * world
     n_ok, it_sum, nf_sum = float(stats[1]), float(stats[2]), float(stats[3])
     total = B * world
+    # the closed loop (config C5) sharded the same way: every rank runs the whole loop for its own rollouts
+    c5_multi = None
+    if world > 1 and args.closed_loop_rollouts > 0:
+        try:
+            c5_multi = closed_loop_c5(args.closed_loop_rollouts, first=rank * args.closed_loop_rollouts, dist=dist)
+        except Exception as e:          # noqa: BLE001
+            c5_multi = {"error": repr(e)}
 
     if rank == 0:
         value = n_ok * args.steps / elapsed             # instance-steps solved to converged/acceptable per second
         ab = alg_bytes(N, M)
         achieved = ab * B / (kern_ms * 1e-3) / 1e9
+        kname = "obca_ipm_kernel_r4" if solver_rows <= 256 else "obca_ipm_kernel_r5" if solver_rows <= 320 else "obca_ipm_kernel_r6"
+        pmc = pmc_summary(kname, B, N, M)
         line = {
             "metric": "OBCA MPC steps/sec (batch) at N=5, 3 obs", "value": value, "unit": "MPC steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -272,18 +337,30 @@ def main():
             "attempted_steps_per_s": total * args.steps / elapsed, "success_rate": n_ok / total, "mean_ipm_iters": it_sum / total, "mean_kkt_factorisations": nf_sum / total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         # HBM bytes per launch from the PMC passes committed under profiles/ (r01i: FETCH_SIZE x2 + WRITE_SIZE)
-                         "traffic": 14.8e6 if (B, N, M) == (8192, 5, 6) else None,
-                         "kernel": "obca_ipm_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_instance": ab,
+                         # HBM bytes per launch measured by the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE x 2,
+                         # the gfx950 correction of the microarchitecture guide, + WRITE_SIZE); null when no pass matches
+                         "traffic": (pmc or {}).get("traffic_bytes"), "traffic_source": (pmc or {}).get("source"),
+                         "valu_busy_frac": (pmc or {}).get("valu_busy_frac"), "wave_wait_frac": (pmc or {}).get("wave_wait_frac"),
+                         "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_instance": ab,
                          "fp64_model_frac": value / world * (nf_sum / total) * (N + 1) * (32 ** 3 / 3 + 2 * 32 ** 2) / 78.6e12
                          if M == 6 else None,
                          "note": "latency/fp64-VALU bound by design (SURVEY 8d): ~1.3 KB of HBM traffic per solve; "
                                  "fp64_model_frac = steps/s x KKT factorisations x (N+1)(s^3/3+2s^2), s=32, over 78.6 TF"},
         }
+        if world == 8 and B == 8192:
+            line["config"]["workload"] += " -- this is config C4 (65 536 scenarios sharded over 8 GPUs, gather only)"
+        if c5_multi is not None:
+            line["closed_loop"] = c5_multi
         if small is not None:
             line["batch_1024"] = small
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
+            try:                                # the reference's own solver, where it exists (it does not in this image)
+                line["ipopt"] = ipopt_leg(batch, N)
+            except Exception as e:              # noqa: BLE001
+                line["ipopt"] = {"error": repr(e)}
+            if line["ipopt"] == "unavailable":
+                line["cpu_baseline"]["note"] = "IPOPT unavailable (`import casadi` fails on this box): the CPU figure is the build's own C restatement of the same interior-point method; the reference publishes 3.7 s per solve at N=10 (src/simulation.py:231)"
             try:
                 line["cpu_structured_core"] = cpu_structured(batch, N)
             except Exception as e:              # noqa: BLE001  (context figure only)

@@ -76,7 +76,8 @@ enum {
     OBCA_STATUS_LINESEARCH = -2,
     OBCA_STATUS_NUMERIC = -3,
     OBCA_STATUS_BAD_BOUNDS = -4,
-    OBCA_STATUS_SKIPPED = -5           /* variant[b] == 0: instance not solved, outputs untouched */
+    OBCA_STATUS_SKIPPED = -5,          /* variant[b] == 0: instance not solved, outputs untouched */
+    OBCA_STATUS_BAD_VARIANT = -6       /* variant[b] not in {0,4,6,8}, or 6 with term == NULL: not solved */
 };
 
 /* return codes */
@@ -101,7 +102,8 @@ void obca_destroy(obca_handle* h);
  *   A     [B,N+1,M,2]    obstacle rows per horizon step   (reference AObs; variant 4 reads step 0 only,
  *   b     [B,N+1,M]       obca.py:969; M = sum m[i])      (reference bObs)
  *   Ts    [B]            base sample time                 (reference Ts)
- *   term  [B,3]          xmin, ymin, ymax of the terminal set, variant 6 only (obca.py:1465-1466)
+ *   term  [B,3]          xmin, ymin, ymax of the terminal set, variant 6 only (obca.py:1465-1466); may be NULL when
+ *                        no instance is variant 6 (a variant-6 instance then gets OBCA_STATUS_BAD_VARIANT)
  * outputs
  *   xopt  [B,3,N+1], uopt [B,2,N], ts_opt [B] (= Topt*Ts for variant 4, Ts otherwise)
  *   status [B] int32, iters [B] int32

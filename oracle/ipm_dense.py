@@ -242,6 +242,9 @@ def _solve_once(p, opts=None, trace=None):
         return max(dual / sd, prim, comp / sc), dual, prim, comp
 
     filt = []
+    npair = (p.N + 1) * p.nObs
+    R_max = 3 + 3 * p.N + 3 + 2 * (p.N + 1) + 4 * p.N + 2 + 2 * npair + (p.N + 1) * (p.M + 4 * p.nObs)
+    filt_cap = 64 if R_max <= 384 else 128
     th0 = theta_of(ch, ge, s, ep, en)
     theta_max = o["theta_max_fact"] * max(1.0, th0)
     theta_min = o["theta_min_fact"] * max(1.0, th0)
@@ -475,6 +478,9 @@ def _solve_once(p, opts=None, trace=None):
         if aug:
             tn, pn_ = (1 - o["gamma_theta"]) * th, phi - o["gamma_phi"] * th
             filt = [(tf, pf) for (tf, pf) in filt if not (tf >= tn and pf >= pn_)]   # drop dominated entries
+            if len(filt) >= filt_cap:            # capacity rule of the kernels (csrc/obca_device.h: OBCA_FILTER_CAP)
+                status = STATUS_NUMERIC
+                break
             filt.append((tn, pn_))
             res.max_filter = max(getattr(res, "max_filter", 0), len(filt))
         a_used = step[0]

@@ -406,6 +406,9 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
     (void)gt_; (void)tmpn;
     double filt_t[MAXFILT], filt_p[MAXFILT];
     int nfilt = 0, status = ST_MAXITER, it = 0, nfact = 0;
+    const int np_ = (N + 1) * p->nO;
+    const int R_max = 3 + 3 * N + 3 + 2 * (N + 1) + 2 * N + 2 * N + 2 + 2 * np_ + (N + 1) * p->M + (N + 1) * 4 * p->nO;
+    const int filt_cap = R_max <= 384 ? 64 : 128;
     for (int i = 0; i < n; ++i) x[i] = 0;
     if (p->freeT) x[iT(p)] = 1.0;
     /* scaling */
@@ -714,7 +717,7 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
                 int w = 0;
                 for (int i = 0; i < nfilt; ++i) if (!(filt_t[i] >= tn && filt_p[i] >= pn)) { filt_t[w] = filt_t[i]; filt_p[w] = filt_p[i]; ++w; }
                 nfilt = w;
-                if (nfilt >= MAXFILT) { status = ST_NUMERIC; break; }
+                if (nfilt >= filt_cap) { status = ST_NUMERIC; break; }   /* same capacity rule as the kernels (csrc/obca_device.h) */
                 filt_t[nfilt] = tn; filt_p[nfilt] = pn; ++nfilt;
             }
             for (int r = 0; r < me; ++r) {

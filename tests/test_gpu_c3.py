@@ -25,7 +25,7 @@ def run(batch, N, mode=None):
     out = s.solve(batch["variant"], batch["x0"], batch["u0"], batch["xref"], batch["A"], batch["b"], batch["Ts"],
                   batch["term"], SolverParams())
     torch.cuda.synchronize()
-    return {k: getattr(out, k).cpu().numpy() for k in ("xopt", "uopt", "ts_opt", "status", "iters")}
+    return {k: getattr(out, k).cpu().numpy() for k in ("xopt", "uopt", "ts_opt", "status", "iters", "info")}
 
 
 def dynamics_residual(x, u, h):
@@ -131,13 +131,23 @@ def test_c3_fixed_time_moving_obstacles():
     assert (x[:, 0, -1] >= b["term"][ok][:, 0] - 1e-7).all()                     # terminal set of obca_mpc6
     assert ((x[:, 1, -1] >= 1 - 1e-7) & (x[:, 1, -1] <= 9 + 1e-7)).all()
     # parity with the dense oracle at a size it finishes in seconds (N = 8, same five obstacles)
-    N2 = 8
-    b2 = sc.make_batch_c3(3, N2, gated=True)
+    N2, B2 = 8, 16
+    b2 = sc.make_batch_c3(B2, N2, gated=True)
     o2 = run(b2, N2)
     ref = c_oracle.solve_batch(6, N2, b2["m"], b2["x0"], b2["u0"], b2["xref"], b2["A"], b2["b"], b2["Ts"], b2["term"],
-                               threads=3)
-    for i in range(3):
+                               threads=min(B2, os.cpu_count() or 1))
+    n_tight = 0
+    for i in range(B2):
         f_ref, f_gpu = ref["status"][i] in (0, 1), o2["status"][i] in (0, 1)
         assert f_ref == f_gpu
-        if f_ref and ref["iters"][i] == o2["iters"][i]:
+        if not f_ref:
+            continue
+        if ref["iters"][i] == o2["iters"][i]:                 # same iterate sequence: 1e-9
             np.testing.assert_allclose(o2["xopt"][i], ref["xopt"][i], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(o2["uopt"][i], ref["uopt"][i], rtol=0, atol=1e-9)
+            n_tight += 1
+        else:                                                 # roundoff flipped a decision on the way: same objective value
+            assert o2["info"][i, 0] == pytest.approx(ref["info"][i, 0], rel=1e-6, abs=1e-9)   # (flat valley: Q = 0.001 I)
+    assert n_tight >= 8                                       # observed 10 of 15 feasible ones
+    # and, whatever the path, every converged answer is a KKT point of the reference-pinned model (N = 8 and N = 20:
+    # tests/test_gpu_certificates.py::test_c3_instances_are_certified_at_N20)

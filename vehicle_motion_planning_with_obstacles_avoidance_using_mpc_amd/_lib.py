@@ -47,6 +47,7 @@ EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", 
 OBCA_MAX_DYN = 4
 RUN, DONE_GOAL, DONE_CAP, DONE_FAILED = 0, 1, 2, 3
 STATUS_SKIPPED = -5
+STATUS_BAD_VARIANT = -6
 
 STATUS_OK, STATUS_ACCEPTABLE, STATUS_INFEASIBLE = 0, 1, 2
 STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NUMERIC, STATUS_BAD_BOUNDS = -1, -2, -3, -4

@@ -291,7 +291,10 @@ class BatchClosedLoop:
         groups = {}
         for idx, variant, args in pending:
             m = tuple(int(args[12][i]) - 1 for i in range(int(args[11])))
-            groups.setdefault((variant == 4, args[4], m), []).append((idx, variant, args))
+            # one launch = one set of solver constants: weights, boxes, footprint and clearance are part of the key
+            const = tuple(np.asarray(args[j], float).round(15).tobytes() for j in (1, 2, 6, 7, 8, 9, 16)) + \
+                tuple(np.asarray(r, float).tobytes() for r in args[3]) + (float(args[15]),)
+            groups.setdefault((variant == 4, args[4], m, const), []).append((idx, variant, args))
         results = {}
         for calls in groups.values():
             for (idx, _, _), res in zip(calls, self._solve_group(calls)):

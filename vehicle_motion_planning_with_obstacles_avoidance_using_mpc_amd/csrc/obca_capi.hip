@@ -101,25 +101,30 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
     h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
     h->mw_ok = !(h->lds_bytes + 64 > 160 * 1024 || h->R_max > 1280); // 256 threads x 3 or 5 rows; 32 B of static LDS
-    if (hipSetDevice(d->device) != hipSuccess) { delete h; return OBCA_E_HIP; }
+    ObcaDeviceGuard guard(d->device);
+    if (!guard.ok) { delete h; return OBCA_E_HIP; }
+    // a kernel whose LDS request the runtime refuses is simply not offered (the lane kernel serves every shape)
     if (h->mw_ok && h->lds_bytes > 64 * 1024 &&
         hipFuncSetAttribute(h->R_max <= 768 ? reinterpret_cast<const void*>(obca_ipm_kernel_mw_r3)
                                             : reinterpret_cast<const void*>(obca_ipm_kernel_mw_r5),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
-        delete h;
-        return OBCA_E_HIP;
+        (void)hipGetLastError();
+        h->mw_ok = false;
     }
     if (h->wave_ok && h->lds_bytes > 64 * 1024) {
         const void* fn = h->R_max <= 256   ? reinterpret_cast<const void*>(obca_ipm_kernel_r4)
                          : h->R_max <= 320 ? reinterpret_cast<const void*>(obca_ipm_kernel_r5)
                                            : reinterpret_cast<const void*>(obca_ipm_kernel_r6);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
-            delete h;
-            return OBCA_E_HIP;
+            (void)hipGetLastError();
+            h->wave_ok = false;
         }
     }
     h->mode = 0;
-    if (const char* e = getenv("OBCA_MODE")) h->mode = atoi(e);
+    if (const char* e = getenv("OBCA_MODE")) {
+        const int m = atoi(e);                                     // out of range or not available for this shape: auto
+        if (m >= 0 && m <= 3 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok)) h->mode = m;
+    }
     h->ws = nullptr; h->d_offm = nullptr;
     h->ws_stride = ((size_t)d->max_batch + 63) / 64 * 64;
     h->ws_doubles = lpi::carve(d->N, d->n_obs, h->M, h->n_max, h->R_max).total;
@@ -137,6 +142,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
 
 extern "C" void obca_destroy(obca_handle* h) {
     if (!h) return;
+    ObcaDeviceGuard guard(h->dims.device);
     if (h->ws) (void)hipFree(h->ws);
     if (h->soc_ws) (void)hipFree(h->soc_ws);
     if (h->d_offm) (void)hipFree(h->d_offm);
@@ -242,6 +248,8 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
                                              iters, info, &L, nullptr, nullptr);
     if (rc != OBCA_OK) return rc;
     if (B == 0) return OBCA_OK;
+    ObcaDeviceGuard guard(h->dims.device);
+    if (!guard.ok) return OBCA_E_HIP;
     // wave kernel (working set in LDS) whenever the shape fits one CU; the lane kernel (working set in an HBM
     // workspace, one instance per lane) takes the shapes beyond the LDS -- measured on MI355X it is latency bound
     // (every access is an L2/HBM round trip at one wave per SIMD) and 4-10x slower where both run

@@ -42,6 +42,12 @@
 #define OBCA_MAX_SOC 4
 #define OBCA_RHO_ESCALATION 100.0   /* obca_mpc4 only: one retry with rho x 100 when elastic variables remain */
 
+/* Line-search filter capacity: a function of the problem SHAPE only, so that every kernel that can run a shape (and the
+   oracles) stops at the same point when the filter fills up (status OBCA_STATUS_NUMERIC): 64 entries for shapes the
+   one-wavefront kernel takes (<= 384 rows: one entry per lane), 128 for larger ones.  IPOPT's filter is unbounded; a
+   solve that fills 64 entries is stalling at the barrier floor. */
+#define OBCA_FILTER_CAP(R_max) ((R_max) <= 384 ? 64 : 128)
+
 #define OBCA_INST_DOUBLES 64   /* LDS reserved for the per-instance constant block (struct Inst) */
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
@@ -72,6 +78,20 @@ struct ObcaLaunch {
     ObcaParamsDev prm;
 };
 
+
+#ifdef __HIPCC__
+// Every entry point that allocates or launches runs on ITS handle's device and leaves the caller's current device alone
+// (two handles on different GPUs in one process; torch.cuda.set_device after construction).
+struct ObcaDeviceGuard {
+    int prev;
+    bool ok;
+    explicit ObcaDeviceGuard(int dev) : prev(-1), ok(true) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~ObcaDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#endif
 
 // internal (not part of the C ABI): the launch descriptor obca_solve_batch builds, for kernels that embed the solver
 int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,

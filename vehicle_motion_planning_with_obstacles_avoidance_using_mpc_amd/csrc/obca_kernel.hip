@@ -1225,6 +1225,13 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         if (lane == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; }
         return;
     }
+    {   // anything but obca_mpc4 / 6 / 8, or obca_mpc6 without its terminal set: a per-instance error, nothing is solved
+        const int v = A.variant[inst];
+        if ((v != 4 && v != 6 && v != 8) || (v == 6 && A.term == nullptr)) {
+            if (lane == 0 && !pass) { A.status[inst] = OBCA_STATUS_BAD_VARIANT; A.iters[inst] = 0; }
+            return;
+        }
+    }
     // Penalty escalation (one, free-time problem only): the l1 penalty is exact only while rho exceeds the multipliers.
     // If obca_mpc4 converges with elastic variables left -- what "infeasible" looks like, but also what a too small rho
     // looks like (the open-loop problem of demo1 at N = 10) -- the caller runs the body a second time (pass = 1) with
@@ -1744,7 +1751,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             if (lane == slot) { f_valid = true; f_th = tn; f_phi = pn; }
 #else
             if (f_valid && f_th >= tn && f_phi >= pn) f_valid = false;          // dominated entries leave
-            const unsigned long long freem = __ballot(!f_valid);                // per wavefront
+            const unsigned long long freem = __ballot(!f_valid && lane < OBCA_FILTER_CAP(A.R_max));   // per wavefront
             const double cand = freem ? (double)((lane & ~63) + __ffsll((long long)freem) - 1) : 1e9;
             const double slot = red_min(cand);                                  // first free entry of the block
             const int full = slot > 1e8 ? 1 : 0;

@@ -48,7 +48,7 @@ struct SP {                      // strided pointer into the workspace
 struct Lay {
     int N, nO, M, NS, n, free_T, variant;
     int r_init, r_dyn, r_term, r_xb, r_ub, r_acc, r_T, r_tx, r_norm, r_dist, r_lam, r_mu, R;
-    int npair;
+    int npair, R_cap;          // R_cap: row count of the shape's largest variant (decides the filter capacity)
     LPI_MEM int ip(int k) const { return k * NS; }
     LPI_MEM int iu(int k) const { return k * NS + 3; }
     LPI_MEM int il(int k) const { return k * NS + (k < N ? 5 : 3); }
@@ -1061,6 +1061,7 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
         S.crot[2 * pr] = e1; S.crot[2 * pr + 1] = e2;
     }
     int nfilt = 0;
+    const int filt_cap = OBCA_FILTER_CAP(L.R_cap);
     double theta_max = 0.0, theta_min = 0.0, delta_w_last = 0.0, tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
     int acc_count = 0, it = 0;
     double fobj_prev = 0.0;
@@ -1302,7 +1303,7 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
                 if (!(a >= tn && b >= pn)) { S.filt[2 * w] = a; S.filt[2 * w + 1] = b; ++w; }
             }
             nfilt = w;
-            if (nfilt >= FILT_MAX) { o.status = OBCA_STATUS_NUMERIC; break; }
+            if (nfilt >= filt_cap) { o.status = OBCA_STATUS_NUMERIC; break; }
             S.filt[2 * nfilt] = tn; S.filt[2 * nfilt + 1] = pn; ++nfilt;
         }
         for (int r = 0; r < L.R; ++r) {
@@ -1390,8 +1391,13 @@ LPI_FN void bind(Sh& S, const Carve& c, double* ws, size_t stride, size_t inst, 
 // thread pool can reuse one contiguous column per thread with stride 1)
 LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t inst, const int* offm, size_t ws_col) {
     if (A.variant[inst] == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; return; }
+    {
+        const int v = A.variant[inst];
+        if ((v != 4 && v != 6 && v != 8) || (v == 6 && A.term == nullptr)) { A.status[inst] = OBCA_STATUS_BAD_VARIANT; A.iters[inst] = 0; return; }
+    }
     Lay L;
     make_layout(L, A.N, A.nO, A.M, A.variant[inst]);
+    L.R_cap = A.R_max;
     const Carve c = carve(A.N, A.nO, A.M, A.n_max, A.R_max);
     Sh S;
     bind(S, c, ws, stride, ws_col, offm);

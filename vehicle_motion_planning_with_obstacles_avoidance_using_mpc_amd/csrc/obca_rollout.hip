@@ -63,7 +63,7 @@ template <class T>
 bool dev_alloc(obca_rollouts* r, T*& p, size_t count) {
     void* q = nullptr;
     if (hipMalloc(&q, sizeof(T) * (count ? count : 1)) != hipSuccess) return false;
-    if (hipMemset(q, 0, sizeof(T) * (count ? count : 1)) != hipSuccess) return false;
+    if (hipMemset(q, 0, sizeof(T) * (count ? count : 1)) != hipSuccess) { (void)hipFree(q); return false; }
     r->allocs.push_back(q);
     p = static_cast<T*>(q);
     return true;
@@ -73,6 +73,7 @@ bool dev_alloc(obca_rollouts* r, T*& p, size_t count) {
 
 extern "C" void obca_rollouts_destroy(obca_rollouts* r) {
     if (!r) return;
+    ObcaDeviceGuard guard(r->dims.device);
     for (void* p : r->allocs) (void)hipFree(p);
     for (int g = 0; g < rollout::MAX_GROUPS; ++g) {
         if (r->solver[g]) obca_destroy(r->solver[g]);
@@ -97,7 +98,8 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     r->ready = false;
     for (int g = 0; g < rollout::MAX_GROUPS; ++g) { r->solver[g] = nullptr; r->gstream[g] = nullptr; r->join[g] = nullptr; }
     r->fork = nullptr;
-    if (hipSetDevice(d->device) != hipSuccess) { delete r; return OBCA_E_HIP; }
+    ObcaDeviceGuard guard(d->device);
+    if (!guard.ok) { delete r; return OBCA_E_HIP; }
     rollout::Dev& D = r->D;
     memset(&D, 0, sizeof(D));
     D.B = d->batch; D.N = d->N; D.n_static = d->n_static; D.n_dyn = d->n_dyn; D.P = d->path_max; D.S = d->max_steps;
@@ -147,6 +149,8 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
                                    void* hip_stream) {
     if (!r || !start || !goal || !path || !path_len || !static_A || !static_b || !params || (r->dims.n_dyn > 0 && !dyn))
         return OBCA_E_INVAL;
+    ObcaDeviceGuard guard(r->dims.device);
+    if (!guard.ok) return OBCA_E_HIP;
     hipStream_t s = (hipStream_t)hip_stream;
     rollout::Dev& D = r->D;
     const size_t B = D.B, N1 = D.N + 1, S = D.S, nd = D.n_dyn;
@@ -213,6 +217,8 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
 
 extern "C" int obca_rollouts_step(obca_rollouts* r, void* hip_stream) {
     if (!r || !r->ready) return OBCA_E_INVAL;
+    ObcaDeviceGuard guard(r->dims.device);
+    if (!guard.ok) return OBCA_E_HIP;
     hipStream_t s = (hipStream_t)hip_stream;
     const rollout::Dev& D = r->D;
     const dim3 grid((D.B + 63) / 64), block(64);
@@ -239,6 +245,8 @@ extern "C" int obca_rollouts_step(obca_rollouts* r, void* hip_stream) {
 
 extern "C" int obca_rollouts_set_warm_start(obca_rollouts* r, int enable, double mu_init) {
     if (!r || (enable && !(mu_init > 0.0))) return OBCA_E_INVAL;
+    ObcaDeviceGuard guard(r->dims.device);
+    if (!guard.ok) return OBCA_E_HIP;
     rollout::Dev& D = r->D;
     if (enable && !D.wz[0]) {
         for (int g = 0; g <= D.n_dyn; ++g) {
@@ -266,6 +274,8 @@ extern "C" int obca_rollouts_set_mode(obca_rollouts* r, int mode) {
 
 extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_stream) {
     if (!r || !r->ready || n_steps < 0) return OBCA_E_INVAL;
+    ObcaDeviceGuard guard(r->dims.device);
+    if (!guard.ok) return OBCA_E_HIP;
     if (n_steps == 0) return OBCA_OK;
     if (r->fused_ok && r->mode == 0) {
         if (r->rows_max <= 256)
@@ -290,6 +300,8 @@ extern "C" int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_
                                   double* x_openloop, int32_t* variant_hist, int32_t* iters_hist, int32_t* status_hist,
                                   double* dyn_hist, int32_t* steps, int32_t* flags, void* hip_stream) {
     if (!r || !r->ready) return OBCA_E_INVAL;
+    ObcaDeviceGuard guard(r->dims.device);
+    if (!guard.ok) return OBCA_E_HIP;
     hipStream_t s = (hipStream_t)hip_stream;
     const rollout::Dev& D = r->D;
     const size_t B = D.B, N1 = D.N + 1, S = D.S, nd = D.n_dyn;

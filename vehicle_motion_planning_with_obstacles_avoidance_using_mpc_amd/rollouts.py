@@ -17,7 +17,8 @@ from .solver import SolverParams
 
 class PackedWorlds:
     """start [B,3], goal [B,2], path [B,3,P], path_len [B], static_A [B,Ms,2], static_b [B,Ms], dyn [B,nDyn,13]"""
-    __slots__ = ("m_static", "n_dyn", "start", "goal", "path", "path_len", "static_A", "static_b", "dyn", "sense_dis")
+    __slots__ = ("m_static", "n_dyn", "start", "goal", "path", "path_len", "static_A", "static_b", "dyn", "sense_dis",
+                 "xL", "xU")
 
     @property
     def batch(self):
@@ -26,6 +27,7 @@ class PackedWorlds:
     def slice(self, lo, hi):
         w = PackedWorlds()
         w.m_static, w.n_dyn, w.sense_dis = self.m_static, self.n_dyn, self.sense_dis
+        w.xL, w.xU = self.xL, self.xU
         for k in ("start", "goal", "path", "path_len", "static_A", "static_b", "dyn"):
             setattr(w, k, getattr(self, k)[lo:hi])
         return w
@@ -79,9 +81,14 @@ def pack_worlds(settings, path_max=None, planner="host"):
     w.path_len = np.zeros(B, dtype=np.int32)
     w.static_A = np.zeros((B, Ms, 2)); w.static_b = np.zeros((B, Ms)); w.dyn = np.zeros((B, nd, 13))
     w.sense_dis = float(settings[0].senseDis)
+    # the position box the reference hands to every solve (setting.xL / xU, src/closed_loop.py:38-39): one per batch
+    w.xL = tuple(float(v) for v in settings[0].xL[:2])
+    w.xU = tuple(float(v) for v in settings[0].xU[:2])
     for i, s in enumerate(settings):
         if [int(v) - 1 for v in s.static_vObs] != m0 or len(s.dyn_obs_info) != nd or float(s.senseDis) != w.sense_dis:
             raise ValueError("setting %d has a different shape than setting 0" % i)
+        if tuple(float(v) for v in s.xL[:2]) != w.xL or tuple(float(v) for v in s.xU[:2]) != w.xU:
+            raise ValueError("setting %d has a different position box (xL, xU) than setting 0: one batch, one map size" % i)
         w.start[i] = np.asarray(s.startPose[:3], float)
         w.goal[i] = np.asarray(s.goalPose[:2], float)
         p = paths[i]
@@ -155,8 +162,10 @@ class DeviceRollouts:
     """B rollouts on one GPU.  ``step()`` enqueues one receding-horizon step of every running rollout;
     ``run()`` all of them; ``read()`` returns state and history (torch tensors on the device)."""
 
-    def __init__(self, worlds, N=5, params=None, Ts0=0.1, max_steps=30, device=None, warm_start=None):
-        """warm_start: None = the reference's cold start of every solve; a float mu_init = start each step whose
+    def __init__(self, worlds, N=6, params=None, Ts0=0.1, max_steps=30, device=None, warm_start=None):
+        """N: horizon of both problems (the reference's committed default is N_free = N_fix = 6, src/closed_loop.py:84,91).
+        params: None = the reference's controller constants with the position box of the worlds (setting.xL / xU).
+        warm_start: None = the reference's cold start of every solve; a float mu_init = start each step whose
         problem shape equals the previous step's from the shifted previous plan (NOT reference behaviour)."""
         import torch
         if not torch.cuda.is_available():
@@ -166,8 +175,9 @@ class DeviceRollouts:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.w = worlds if isinstance(worlds, PackedWorlds) else pack_worlds(worlds)
         self.N, self.max_steps, self.Ts0 = int(N), int(max_steps), float(Ts0)
-        self.params = params or SolverParams()
-        self._dims = rollout_dims(self.w, N, max_steps, self.device.index or 0)
+        self.params = params or SolverParams(xL=getattr(self.w, "xL", (0.0, 0.0)), xU=getattr(self.w, "xU", (39.0, 10.0)))
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._dims = rollout_dims(self.w, N, max_steps, dev_index)
         h = ctypes.c_void_p()
         _lib.check(self.lib.obca_rollouts_create(ctypes.byref(self._dims), ctypes.byref(h)))
         self._h = h

@@ -24,3 +24,16 @@ def gather_outputs(dist, local, total, world):
         dist.all_gather(parts, pad)
         out[name] = torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
     return out
+
+
+def shard_worlds(worlds, world, rank):
+    """the contiguous slice of a ``rollouts.PackedWorlds`` batch owned by ``rank``: every rank runs the WHOLE closed
+    loop (harness + solves, obca_rollouts_run) for its own rollouts; nothing is exchanged until the histories are
+    gathered."""
+    lo, hi = shard_bounds(worlds.batch, world, rank)
+    return worlds.slice(lo, hi)
+
+
+def gather_rollouts(dist, local, total, world):
+    """all_gather of the history dict of ``DeviceRollouts.read()`` (every entry has the rollout dimension first)"""
+    return gather_outputs(dist, local, total, world)

@@ -75,7 +75,8 @@ class BatchSolver:
         self.n_obs = len(self.m)
         self.max_batch = int(max_batch)
         d = _lib.ObcaDims()
-        d.N, d.n_obs, d.max_batch, d.device = self.N, self.n_obs, self.max_batch, self.device.index or 0
+        d.N, d.n_obs, d.max_batch = self.N, self.n_obs, self.max_batch
+        d.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         for i, v in enumerate(self.m):
             d.m[i] = v
         self._dims = d
