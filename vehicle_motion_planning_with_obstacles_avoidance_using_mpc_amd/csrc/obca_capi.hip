@@ -69,6 +69,7 @@ int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off)
     }
     take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
     take(48); take(64); take(8);                               // FG (one stage), Mall, mall
+    take(32);                // lsv: iteration-level and line-search scalars
     take(8);                 // offm
     inst_off = (int)t;
     take(OBCA_INST_DOUBLES);

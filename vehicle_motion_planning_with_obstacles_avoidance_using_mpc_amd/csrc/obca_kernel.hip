@@ -136,6 +136,7 @@ struct Sh {
     double *Lall, *lall, *Sloc, *Y;
     double *Pk, *qk, *Kk, *kapk, *Mik;
     double *FG, *Mall, *mall;
+    double* lsv;                             // line-search scalars parked in LDS across a corrected (second-order) solve
     int* offm;
 };
 
@@ -1279,6 +1280,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         }
         S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
         S.FG = take(48); S.Mall = take(64); S.mall = take(8);
+        S.lsv = take(32);
         S.offm = reinterpret_cast<int*>(take(8));
         S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
     }
@@ -1355,14 +1357,21 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     SYNC();
     int status = OBCA_STATUS_MAXITER;
     int it = 0, nfact = 0;
-    double E0 = INFINITY, sf = 1.0, rho = O.rho;
+    double sf = 1.0, rho = O.rho;
+    // Iteration-level scalars that the factorisation never reads are kept in LDS (S.lsv), not in registers: written by
+    // thread 0, read back where they are used (a handful of broadcast reads per iteration) -- about 25 registers less
+    // across the factorisation, which is what lets the second-order correction fit without scratch.
+    enum { IV_E0 = 11, IV_THMAX, IV_THMIN, IV_EMAX, IV_CNTNZ, IV_CNTROWS, IV_DWLAST, IV_FPREV, IV_F, IV_N };
+#define PUT(idx, v) do { if (lane == 0) S.lsv[idx] = (v); } while (0)
+#define GET(idx) (S.lsv[idx])
+    PUT(IV_E0, INFINITY);
     bool bad_bounds = false;
 
     // objective scaling: IPOPT's gradient rule applied to f + rho*sum(p+n)
     for (int t = lane; t < L.n; t += NT) S.gf[t] = 0.0;        // the objective does not depend on lambda, mu
     SYNC();
     eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
-    double f = eval_objective<true>(L, S, in, S.x, 1.0, lane);
+    double f0 = eval_objective<true>(L, S, in, S.x, 1.0, lane);
     {
         double gm = 0.0;
         for (int t = lane; t < L.n; t += NT) gm = dmaxabs(gm, S.gf[t]);
@@ -1371,7 +1380,8 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         rho = O.rho * sf;
     }
     SYNC();
-    f = eval_objective<true>(L, S, in, S.x, sf, lane);
+    f0 = eval_objective<true>(L, S, in, S.x, sf, lane);
+    PUT(IV_F, f0);
     double mu = warm ? A.warm_mu : OBCA_MU_INIT;
     // rows: bounds, slacks with bound push, elastic variables on their 1-d central path
     Rows<RPL> W;
@@ -1439,43 +1449,57 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     }
     cnt_nz = red_sum(cnt_nz);
     cnt_rows = red_sum(cnt_rows) + 2.0 * L.npair;
+    PUT(IV_CNTNZ, cnt_nz); PUT(IV_CNTROWS, cnt_rows);
 
     // filter: one entry per lane
     bool f_valid = false;
     double f_th = 0.0, f_phi = 0.0;
-    double theta_max = 0.0, theta_min = 0.0;
-    double delta_w_last = 0.0, tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
+    double tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
+    PUT(IV_DWLAST, 0.0); PUT(IV_EMAX, 0.0);
     int acc_count = 0;
-    double fobj_prev = 0.0;
     bool have_prev = false;
-    double elastic_max = 0.0;
 
 #ifdef OBCA_PROFILE
     long long prof_t[20];
     for (int i = 0; i < 20; ++i) prof_t[i] = 0;
 #endif
+    // IPOPT's second-order correction (max_soc = 4, kappa_soc = 0.99): when the FIRST trial step of a line search is rejected
+    // without reducing the constraint violation, up to max_soc corrected steps are tried -- same matrix (same delta_w),
+    // right-hand side from the accumulated residuals c_soc (rotation rows, kept in S.crot) and g_soc (rows, HBM scratch
+    // A.soc_ws) -- before the step length is halved.  A corrected solve is ANOTHER PASS of this iteration loop with
+    // soc_pass set (the error evaluation and the barrier update are skipped, `it` does not advance), so that the one copy
+    // of the solve pipeline serves both and no second loop is wrapped around the factorisation: such a loop kept ~130
+    // more registers alive in the hot path (measured: 512 B of scratch per lane, 350 MB of HBM traffic per launch).  The
+    // scalars of the interrupted line search wait in LDS (S.lsv), the original direction in the HBM scratch; rare (~1 line
+    // search in 2000 on the C2 workload).
+    enum { LS_TH = 0, LS_FOBJ, LS_DW, LS_AZ, LS_DPHI, LS_PHI, LS_AMIN, LS_PWTH, LS_PWDPHI, LS_ALPHA, LS_THOLD };
+    bool soc_pass = false, use_soc = false, first_trial = true;
+    int soc_it = 0;
     PROF_DECL
     if (bad_bounds) status = OBCA_STATUS_BAD_BOUNDS;
     else
     for (it = 0; it <= max_iter; ++it) {
         PROF(11)
+        double th = 0.0, fobj = 0.0, delta_w = 0.0;
+        if (!soc_pass) {
         // ---- gradient of the Lagrangian and optimality error ------------------------------------------
         gather_grad(L, S, in, S.y, S.bx, lane);                    // bx doubles as scratch for grad_x L here
-        double rxmax = 0.0, crotmax = 0.0, nusum = 0.0, th = 0.0, pnsum = 0.0;
+        double rxmax = 0.0, crotmax = 0.0, nusum = 0.0, pnsum = 0.0;
         for (int t = lane; t < L.n; t += NT) rxmax = dmaxabs(rxmax, S.bx[t]);
         for (int t = lane; t < 2 * L.npair; t += NT) { crotmax = dmaxabs(crotmax, S.crot[t]); nusum += fabs(S.nu[t]); th += fabs(S.crot[t]); }
         rxmax = red_max(rxmax); crotmax = red_max(crotmax); nusum = red_sum(nusum);
-        const ErrFirst ef = ipm_errors_first<RPL>(L, S, W, mu, rho, rxmax, crotmax, nusum, th, cnt_nz, cnt_rows, lane);
-        th = ef.th; pnsum = ef.pnsum; elastic_max = ef.emax;
+        const ErrFirst ef = ipm_errors_first<RPL>(L, S, W, mu, rho, rxmax, crotmax, nusum, th, GET(IV_CNTNZ), GET(IV_CNTROWS), lane);
+        th = ef.th; pnsum = ef.pnsum; PUT(IV_EMAX, ef.emax);
         const Err e0 = ef.e0;
-        E0 = e0.E;
+        const double E0 = e0.E;
+        PUT(IV_E0, E0);
         if (it == 0) {
-            theta_max = OBCA_THETA_MAX_FACT * fmax(1.0, th);
-            theta_min = OBCA_THETA_MIN_FACT * fmax(1.0, th);
+            PUT(IV_THMAX, OBCA_THETA_MAX_FACT * fmax(1.0, th));
+            PUT(IV_THMIN, OBCA_THETA_MIN_FACT * fmax(1.0, th));
         }
         if (E0 <= O.tol && e0.dual <= 1.0 && e0.prim <= 1e-4 && e0.comp <= 1e-4) { status = OBCA_STATUS_OK; break; }
-        const double fobj = f + rho * pnsum;
-        const double objchg = have_prev ? fabs(fobj - fobj_prev) / fmax(1.0, fabs(fobj)) : INFINITY;
+        fobj = GET(IV_F) + rho * pnsum;
+        const double objchg = have_prev ? fabs(fobj - GET(IV_FPREV)) / fmax(1.0, fabs(fobj)) : INFINITY;
         if (E0 <= acc_tol && e0.dual <= 1e10 && e0.prim <= 1e-2 && e0.comp <= 1e-2 && objchg <= acc_objchg) {
             if (++acc_count >= OBCA_ACCEPTABLE_ITER) { status = OBCA_STATUS_ACCEPTABLE; break; }
         } else acc_count = 0;
@@ -1494,34 +1518,24 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 f_valid = false;
             }
         }
+        } else {
+            th = S.lsv[LS_TH]; fobj = S.lsv[LS_FOBJ]; delta_w = S.lsv[LS_DW];
+            (void)eval_objective<true>(L, S, in, S.x, sf, lane);   // the trial evaluation left ITS gradient in gf
+        }
         PROF(1)
-        // ---- Newton step with inertia correction, backtracking filter line search with second-order correction ------
-        // One copy of the solve pipeline serves the regular step (inertia loop) and IPOPT's second-order correction
-        // (max_soc = 4, kappa_soc = 0.99): when the FIRST trial step is rejected without reducing the constraint
-        // violation, up to max_soc corrected steps are tried -- same matrix (same delta_w), right-hand side from the
-        // accumulated residuals c_soc (rotation rows, kept in S.crot) and g_soc (rows, HBM scratch) -- before the step length
-        // is halved.  While a corrected direction is tried (use_soc) it sits in S.dx / W.dy / S.dnu and the original one
-        // waits in the HBM scratch A.soc_ws (rare path: ~1 line search in 2000 on the C2 workload).
-        double* const ws_dxo = A.soc_ws ? A.soc_ws + (size_t)inst * (A.n_max + 2 * A.R_max + 2 * L.npair) : nullptr;
-        double* const ws_dyo = ws_dxo + A.n_max;
-        double* const ws_gsoc = ws_dyo + A.R_max;
-        double* const ws_dnuo = ws_gsoc + A.R_max;
+        // ---- Newton step with inertia correction -----------------------------------------------------------
+#define ws_dxo (A.soc_ws + (size_t)inst * (A.n_max + 2 * A.R_max + 2 * L.npair))
+#define ws_dyo (ws_dxo + A.n_max)
+#define ws_gsoc (ws_dyo + A.R_max)
+#define ws_dnuo (ws_gsoc + A.R_max)
         const int max_soc = A.soc_ws ? O.max_soc : 0;
-        double delta_w = 0.0;
-        bool first_try = true;
-        int fail = 0;
-        double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0, alpha_min = 0.0, pw_th = 0.0, pw_dphi = 1.0;
-        double alpha = 1.0, a_try = 1.0, f_t = f, th_old = 0.0;
-        bool accepted = false, aug = false, first_trial = true, use_soc = false, soc_solve = false;
-        int soc_it = 0;
-        for (;;) {                                 // solve (regular or corrected), then line search; a correction comes back here
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {       // unconditional writes end the live ranges of the last step data,
             W.dy[j] = 0.0; W.iDs[j] = 0.0; W.iDp[j] = 0.0; W.iDn[j] = 0.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
         }                                      // so they do not occupy registers across the factorisation
-        if (soc_solve) {
-            (void)eval_objective<true>(L, S, in, S.x, sf, lane);   // the trial evaluation left ITS gradient in gf
-        }
+        bool first_try = true;
+        int fail = 0;
+        const double dw_last = GET(IV_DWLAST);
         for (;;) {
 #pragma unroll
             for (int j = 0; j < RPL; ++j) {
@@ -1532,7 +1546,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                     const double lo_ = S.Lb[r], up_ = S.Ub[r];
                     const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], y, W.zL[j], W.zU[j], W.zp[j],
                                           W.zn[j], mu, rho, delta_w);
-                    const double rg = soc_solve ? ws_gsoc[r] : W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j];
+                    const double rg = soc_pass ? ws_gsoc[r] : W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j];
                     const double gh = rg + q.rs * q.iDs + q.rp * q.iDp - q.rn * q.iDn;
                     const double Ei = 1.0 / (q.iDs + q.iDp + q.iDn);
                     S.Einv[r] = Ei;
@@ -1554,20 +1568,19 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
 #endif
             PROF(5)
             ++nfact;
-            if (!bad || soc_solve) break;          // a corrected solve reuses the accepted delta_w: same matrix, same pivots
+            if (!bad || soc_pass) break;           // a corrected solve reuses the accepted delta_w: same matrix, same pivots
             if (first_try) {
-                delta_w = (delta_w_last == 0.0) ? OBCA_DELTA_W_0 : fmax(OBCA_DELTA_W_MIN, OBCA_KAPPA_W_MINUS * delta_w_last);
+                delta_w = (dw_last == 0.0) ? OBCA_DELTA_W_0 : fmax(OBCA_DELTA_W_MIN, OBCA_KAPPA_W_MINUS * dw_last);
                 first_try = false;
             } else {
-                delta_w *= (delta_w_last == 0.0) ? OBCA_KAPPA_W_PLUS_BAR : OBCA_KAPPA_W_PLUS;
+                delta_w *= (dw_last == 0.0) ? OBCA_KAPPA_W_PLUS_BAR : OBCA_KAPPA_W_PLUS;
             }
             if (delta_w > OBCA_DELTA_W_MAX) { fail = 1; break; }
         }
-        if (fail) break;
-        if (!soc_solve && delta_w > 0.0) delta_w_last = delta_w;
-        // ---- row steps, step lengths, directional derivative (the corrected solve only needs its own primal step length)
-        {
-        double am = 1.0, az = 1.0, dph = 0.0, ph = 0.0;
+        if (fail) { status = OBCA_STATUS_NUMERIC; break; }
+        if (!soc_pass && delta_w > 0.0) PUT(IV_DWLAST, delta_w);
+        // ---- row steps, step lengths, directional derivative (a corrected solve only needs its own primal step length)
+        double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0;
         for (int r = lane; r < L.R; r += NT)
             S.tmp[r] = row_soft(L, r) ? S.dy[r] : (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r];
 #pragma unroll
@@ -1592,49 +1605,51 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 double gs = eq ? 0.0 : W.rs[j] + W.y[j];
                 if (hasL) {
                     const double sl = s - lo_, zL = W.zL[j];
-                    if (ds < 0.0) am = fmin(am, -tau * sl / ds);
+                    if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
                     const double dz = (mu - zL * ds) / sl - zL;
-                    if (dz < 0.0) az = fmin(az, -tau * zL / dz);
+                    if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
                 }
                 if (hasU) {
                     const double su = up_ - s, zU = W.zU[j];
-                    if (ds > 0.0) am = fmin(am, tau * su / ds);
+                    if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
                     const double dz = (mu + zU * ds) / su - zU;
-                    if (dz < 0.0) az = fmin(az, -tau * zU / dz);
+                    if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
                 }
-                if (dp < 0.0) am = fmin(am, -tau * p / dp);
-                if (dn < 0.0) am = fmin(am, -tau * n / dn);
+                if (dp < 0.0) a_max = fmin(a_max, -tau * p / dp);
+                if (dn < 0.0) a_max = fmin(a_max, -tau * n / dn);
                 const double zp = W.zp[j], zn = W.zn[j];
                 const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
-                if (dzp < 0.0) az = fmin(az, -tau * zp / dzp);
-                if (dzn < 0.0) az = fmin(az, -tau * zn / dzn);
-                if (!soc_solve) {
-                    ph += w * row_barrier(lo_, up_, eq, s, p, n, mu, rho);
-                    dph += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
-                }
+                if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
+                if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
+                phi += w * row_barrier(lo_, up_, eq, s, p, n, mu, rho);
+                dphi += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
             }
         }
-        am = red_min(am);
-        if (soc_solve) {
-            a_try = am;                            // fraction-to-boundary step of the corrected direction
-        } else {
-            for (int t = lane; t < L.n; t += NT) dph += S.gf[t] * S.dx[t];
-            a_max = am; a_z = red_min(az); dphi = red_sum(dph); phi = red_sum(ph) + f;
-            // the two powers of the switching condition do not depend on the step length: once per iteration, not per trial
-            pw_th = 0.0; pw_dphi = 1.0;
+        for (int t = lane; t < L.n; t += NT) dphi += S.gf[t] * S.dx[t];
+        a_max = red_min(a_max); a_z = red_min(a_z); dphi = red_sum(dphi); phi = red_sum(phi) + GET(IV_F);
+        double alpha_min;
+        // the two powers of the switching condition do not depend on the step length: once per iteration, not per trial
+        double pw_th = 0.0, pw_dphi = 1.0;
+        double alpha = a_max, a_try = a_max, th_old = 0.0;
+        if (!soc_pass) {
             if (dphi < 0.0) {
                 pw_th = dpow(th, OBCA_S_THETA);
                 pw_dphi = dpow(-dphi, OBCA_S_PHI);
                 double c = fmin(OBCA_GAMMA_THETA, OBCA_GAMMA_PHI * th / (-dphi));
-                if (th <= theta_min) c = fmin(c, OBCA_DELTA * pw_th / pw_dphi);
+                if (th <= GET(IV_THMIN)) c = fmin(c, OBCA_DELTA * pw_th / pw_dphi);
                 alpha_min = OBCA_GAMMA_ALPHA * c;
             } else alpha_min = OBCA_GAMMA_ALPHA * OBCA_GAMMA_THETA;
-            alpha = a_max; a_try = a_max;
+            first_trial = true; use_soc = false; soc_it = 0;
+        } else {                                   // corrected direction: its own step length, everything else as parked
+            a_try = a_max;
+            a_z = S.lsv[LS_AZ]; dphi = S.lsv[LS_DPHI]; phi = S.lsv[LS_PHI]; alpha_min = S.lsv[LS_AMIN];
+            pw_th = S.lsv[LS_PWTH]; pw_dphi = S.lsv[LS_PWDPHI]; alpha = S.lsv[LS_ALPHA]; th_old = S.lsv[LS_THOLD];
         }
-        }
+        soc_pass = false;
         PROF(6)
         // ---- backtracking filter line search ---------------------------------------------------------------
-        soc_solve = false;
+        double f_t = 0.0;
+        bool accepted = false, aug = false;
         for (;;) {
             for (int t = lane; t < L.n; t += NT) S.xt[t] = S.x[t] + a_try * S.dx[t];
             SYNC();
@@ -1669,13 +1684,13 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             aug = false;
             const bool finite = isfinite(phi_t) && isfinite(th_t);
 #if OBCA_NT == 64
-            const bool blocked = (th_t >= theta_max) || (__any(f_valid && th_t >= f_th && phi_t >= f_phi) != 0);
+            const bool blocked = (th_t >= GET(IV_THMAX)) || (__any(f_valid && th_t >= f_th && phi_t >= f_phi) != 0);
 #else               // one filter entry per thread (NT entries)
-            const bool blocked = (th_t >= theta_max) || red_or(f_valid && th_t >= f_th && phi_t >= f_phi);
+            const bool blocked = (th_t >= GET(IV_THMAX)) || red_or(f_valid && th_t >= f_th && phi_t >= f_phi);
 #endif
             if (finite && !blocked) {
                 const bool switching = dphi < 0.0 && alpha * pw_dphi > OBCA_DELTA * pw_th;
-                if (th <= theta_min && switching) {
+                if (th <= GET(IV_THMIN) && switching) {
                     ok = phi_t <= phi + OBCA_ETA_PHI * alpha * dphi + 10.0 * 2.220446049250313e-16 * fabs(phi);
                 } else {
                     ok = (th_t <= (1.0 - OBCA_GAMMA_THETA) * th) || (phi_t <= phi - OBCA_GAMMA_PHI * th);
@@ -1724,21 +1739,23 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                     for (int t = lane; t < 2 * L.npair; t += NT) ws_dnuo[t] = S.dnu[t];
                 }
                 for (int t = lane; t < 2 * L.npair; t += NT) S.crot[t] = cf * S.crot[t] + S.bx[t];
-                th_old = th_t;
+                if (lane == 0) {
+                    S.lsv[LS_TH] = th; S.lsv[LS_FOBJ] = fobj; S.lsv[LS_DW] = delta_w; S.lsv[LS_AZ] = a_z; S.lsv[LS_DPHI] = dphi;
+                    S.lsv[LS_PHI] = phi; S.lsv[LS_AMIN] = alpha_min; S.lsv[LS_PWTH] = pw_th; S.lsv[LS_PWDPHI] = pw_dphi;
+                    S.lsv[LS_ALPHA] = alpha; S.lsv[LS_THOLD] = th_t;
+                }
                 use_soc = true;
-                soc_solve = true;
+                soc_pass = true;
                 ++soc_it;
                 __threadfence_block();
                 SYNC();
-                break;                              // to the solve with the corrected right-hand side
+                break;                              // another pass of the iteration loop with the corrected right-hand side
             }
             alpha *= 0.5;
             a_try = alpha;
             if (alpha < alpha_min) break;
         }
-        if (!soc_solve) break;
-        }
-        if (fail) { status = OBCA_STATUS_NUMERIC; break; }
+        if (soc_pass) { --it; continue; }
         PROF(7)
         if (!accepted) { status = OBCA_STATUS_LINESEARCH; break; }
         if (aug) {
@@ -1802,7 +1819,11 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         for (int t = lane; t < 2 * L.npair; t += NT) { S.nu[t] += a_try * S.dnu[t]; S.crot[t] = S.bx[t]; }
         for (int t = lane; t < L.n; t += NT) S.x[t] = S.xt[t];
         SYNC();
-        fobj_prev = fobj;
+#undef ws_dxo
+#undef ws_dyo
+#undef ws_gsoc
+#undef ws_dnuo
+        PUT(IV_FPREV, fobj);
         have_prev = true;
         PROF(8)
         // ---- the new iterate IS the accepted trial point: its geometry (ctt/stt/cct), row values (tmp) and rotation
@@ -1814,7 +1835,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             const int r = lane + NT * j;
             if (r < L.R) W.g[j] = S.tmp[r];
         }
-        f = f_t;                  // objective and its gradient (gf) came with the accepted trial as well
+        PUT(IV_F, f_t);           // objective and its gradient (gf) came with the accepted trial as well
         SYNC();
         PROF(9)
     }
@@ -1822,7 +1843,8 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     if (A.prof && lane == 0) for (int i = 0; i < 20; ++i) A.prof[(size_t)inst * 20 + i] = (double)prof_t[i];
 #endif
 
-    if ((status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE) && elastic_max > O.feas_tol)
+    SYNC();
+    if ((status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE) && GET(IV_EMAX) > O.feas_tol)
         status = OBCA_STATUS_INFEASIBLE;
 
     if (FROM_MEMORY) {
@@ -1862,7 +1884,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             A.iters[inst] = it + (pass ? A.iters[inst] : 0);
             if (A.info) {
                 double* io = A.info + (size_t)inst * 4;
-                io[0] = f / sf; io[1] = elastic_max; io[2] = E0; io[3] = (double)nfact + (pass ? io[3] : 0.0);
+                io[0] = GET(IV_F) / sf; io[1] = GET(IV_EMAX); io[2] = GET(IV_E0); io[3] = (double)nfact + (pass ? io[3] : 0.0);
             }
         }
     }
