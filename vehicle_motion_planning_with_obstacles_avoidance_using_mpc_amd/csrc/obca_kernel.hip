@@ -1361,7 +1361,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     // Iteration-level scalars that the factorisation never reads are kept in LDS (S.lsv), not in registers: written by
     // thread 0, read back where they are used (a handful of broadcast reads per iteration) -- about 25 registers less
     // across the factorisation, which is what lets the second-order correction fit without scratch.
-    enum { IV_E0 = 11, IV_THMAX, IV_THMIN, IV_EMAX, IV_CNTNZ, IV_CNTROWS, IV_DWLAST, IV_FPREV, IV_F, IV_N };
+    enum { IV_E0 = 11, IV_THMAX, IV_THMIN, IV_EMAX, IV_CNTNZ, IV_CNTROWS, IV_DWLAST, IV_FPREV, IV_F, IV_TAU, IV_N };
 #define PUT(idx, v) do { if (lane == 0) S.lsv[idx] = (v); } while (0)
 #define GET(idx) (S.lsv[idx])
     PUT(IV_E0, INFINITY);
@@ -1454,7 +1454,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     // filter: one entry per lane
     bool f_valid = false;
     double f_th = 0.0, f_phi = 0.0;
-    double tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
+    PUT(IV_TAU, fmax(OBCA_TAU_MIN, 1.0 - mu));
     PUT(IV_DWLAST, 0.0); PUT(IV_EMAX, 0.0);
     int acc_count = 0;
     bool have_prev = false;
@@ -1514,7 +1514,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 first_mu = false;
                 if (em.E > OBCA_KAPPA_EPS * mu) break;
                 mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, mu * sqrt(mu)));      // mu^theta_mu, theta_mu = 1.5
-                tau = fmax(OBCA_TAU_MIN, 1.0 - mu);
+                PUT(IV_TAU, fmax(OBCA_TAU_MIN, 1.0 - mu));
                 f_valid = false;
             }
         }
@@ -1581,6 +1581,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         if (!soc_pass && delta_w > 0.0) PUT(IV_DWLAST, delta_w);
         // ---- row steps, step lengths, directional derivative (a corrected solve only needs its own primal step length)
         double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0;
+        const double tau = GET(IV_TAU);
         for (int r = lane; r < L.R; r += NT)
             S.tmp[r] = row_soft(L, r) ? S.dy[r] : (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r];
 #pragma unroll
