@@ -168,7 +168,7 @@ int64_t obca_lds_bytes(const obca_dims* dims);
  * for the moving rectangles (src/demo_setting.py:457-473, src/model_obstacle.py:37-102), the variant dispatch
  * with the mpc6 -> mpc8 fallback (:380-398) and the state advance (:400-432).  Quirks kept: q7 (Ts overwritten
  * after a fixed-time step), q8 (vertex lists of present obstacles are not filtered by the lidar gate), cold start
- * every solve, stop after max_steps (30) steps.  Restriction: N_free == N_fix == N (the reference default is 6/6).
+ * every solve, stop after max_steps (30) steps.  N_free = N, N_fix = N_fix (default: equal, the reference's 6/6).
  *
  * Static obstacles are passed as their half-space rows (host side: obstacle_H_Represent); moving obstacles as the
  * reference's 11-tuple [cx, cy, theta, length, width, speed, end_x, end_y, end_theta, t_start, t_end] followed by
@@ -186,6 +186,11 @@ typedef struct obca_rollout_dims {
     int32_t batch;                     /* rollouts                                                  */
     int32_t max_steps;                 /* 30 in the reference (src/closed_loop.py:431)              */
     int32_t device;
+    int32_t N_fix;                     /* horizon of the fixed-time problem (reference N_fix); 0 = N.  Must be a multiple of
+                                          N (the reference resamples the reference plan by int(N_fix/N_free),
+                                          src/closed_loop.py:570-587) with N_fix - 5 <= N (its shift-in of the previous plan,
+                                          :363-364, reads N_fix - 5 + 1 columns of a free-time plan; the reference raises
+                                          IndexError beyond that, e.g. at 6/12)                       */
 } obca_rollout_dims;
 
 typedef struct obca_rollouts obca_rollouts;
@@ -221,7 +226,8 @@ int obca_rollouts_set_mode(obca_rollouts* r, int mode);
 int obca_rollouts_set_warm_start(obca_rollouts* r, int enable, double mu_init);
 
 /* Copy state and history to caller-owned DEVICE buffers (any may be NULL): x_closed [B,max_steps+1,3],
- * u_closed [B,max_steps,2], T_closed [B,max_steps], x_openloop [B,max_steps,3,N+1], variant_hist [B,max_steps]
+ * u_closed [B,max_steps,2], T_closed [B,max_steps], x_openloop [B,max_steps,3,max(N,N_fix)+1] (a free-time
+ * plan fills its first N+1 columns), variant_hist [B,max_steps]
  * int32 (4/6/8 as solved, 0 = no step), iters_hist [B,max_steps] int32, status_hist [B,max_steps] int32 (solver
  * status of the step's last solve), dyn_hist [B,max_steps,n_dyn,4]
  * (cx, cy, present, sensed), steps [B] int32 (successful steps), flags [B] int32. */

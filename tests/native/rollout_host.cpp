@@ -10,26 +10,28 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
                                 double sense_dis, const HostParams* hp, int n_steps,
                                 double* x_closed, double* u_closed, double* T_closed, double* x_openloop,
                                 int* variant_hist, int* iters_hist, int* status_hist, double* dyn_hist, int* steps, int* flags,
-                                double* xref_hist /* [B,S,3,N+1] solver reference of every step, may be NULL */,
+                                double* xref_hist /* [B,S,3,max(N,N_fix)+1] solver reference of every step, may be NULL */,
                                 double warm_mu /* > 0: warm start as obca_rollouts_set_warm_start does */) {
     using namespace rollout;
     Dev D;
     memset(&D, 0, sizeof(D));
     D.B = d->batch; D.N = d->N; D.n_static = d->n_static; D.n_dyn = d->n_dyn; D.P = d->path_max; D.S = d->max_steps;
+    D.Nf = d->N_fix > 0 ? d->N_fix : d->N;
+    D.Nm = D.Nf > D.N ? D.Nf : D.N;
     D.Ms = 0;
     for (int i = 0; i < d->n_static; ++i) D.Ms += d->m_static[i];
     D.sense_dis = sense_dis; D.ego_l = hp->ego[0]; D.ego_w = hp->ego[1];
-    const size_t B = D.B, N1 = D.N + 1, N = D.N, S = D.S, nd = D.n_dyn;
+    const size_t B = D.B, N1 = D.N + 1, S = D.S, nd = D.n_dyn, Nm1 = D.Nm + 1, Nf1 = D.Nf + 1;
     std::vector<std::vector<double>> dv;
     std::vector<std::vector<int>> iv;
     auto da = [&](size_t n) { dv.emplace_back(n ? n : 1, 0.0); return dv.back().data(); };
     auto ia = [&](size_t n) { iv.emplace_back(n ? n : 1, 0); return iv.back().data(); };
     D.goal = goal; D.path = path; D.path_len = path_len; D.As = As; D.bs = bs;
-    D.x0 = da(B * 3); D.u0 = da(B * 2); D.Ts = da(B); D.Ts_opt = da(B); D.xprev = da(B * 3 * N1); D.dyn = da(B * nd * DYN_W);
-    D.k = ia(B); D.flags = ia(B); D.sel = ia(B); D.xref = da(B * 3 * N1); D.term = da(B * 3);
+    D.x0 = da(B * 3); D.u0 = da(B * 2); D.Ts = da(B); D.Ts_opt = da(B); D.xprev = da(B * 3 * Nm1); D.dyn = da(B * nd * DYN_W);
+    D.k = ia(B); D.flags = ia(B); D.sel = ia(B); D.xref = da(B * 3 * N1); D.xref_fix = da(B * 3 * Nf1); D.term = da(B * 3);
     D.xc = x_closed; D.uc = u_closed; D.Tc = T_closed; D.xol = x_openloop; D.dh = dyn_hist; D.vh = variant_hist; D.ih = iters_hist; D.sh = status_hist;
     for (int g = 0; g <= D.n_dyn; ++g) {
-        const size_t Mg = D.Ms + 4 * g;
+        const size_t Mg = D.Ms + 4 * g, N = g == 0 ? D.N : D.Nf, N1 = N + 1;
         D.var[g] = ia(B); D.var8[g] = ia(B); D.A[g] = da(B * N1 * Mg * 2); D.b[g] = da(B * N1 * Mg);
         D.xopt[g] = da(B * 3 * N1); D.uopt[g] = da(B * 2 * N); D.ts[g] = da(B);
         D.status[g] = ia(B); D.iters[g] = ia(B); D.status8[g] = ia(B); D.iters8[g] = ia(B);
@@ -41,20 +43,25 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
         for (int b = 0; b < D.B; ++b) {
             const int k = D.k[b];
             prepare(D, b);
-            if (xref_hist && D.flags[b] == OBCA_RUN)
-                for (size_t t = 0; t < 3 * N1; ++t) xref_hist[((size_t)b * S + k) * 3 * N1 + t] = D.xref[(size_t)b * 3 * N1 + t];
+            if (xref_hist && D.flags[b] == OBCA_RUN) {       // [B,S,3,Nm+1]: the reference window the solver of this step is given
+                const bool fr = D.sel[b] == 0;
+                const size_t n1 = fr ? N1 : Nf1;
+                const double* src = fr ? D.xref + (size_t)b * 3 * N1 : D.xref_fix + (size_t)b * 3 * Nf1;
+                for (size_t j = 0; j < 3; ++j)
+                    for (size_t t = 0; t < n1; ++t) xref_hist[(((size_t)b * S + k) * 3 + j) * Nm1 + t] = src[j * n1 + t];
+            }
         }
         for (int g = 0; g <= D.n_dyn; ++g) {
             int m[OBCA_MAX_OBST];
             for (int i = 0; i < d->n_static; ++i) m[i] = d->m_static[i];
             for (int i = 0; i < g; ++i) m[d->n_static + i] = 4;
-            int rc = lpi_host_solve_batch_warm(D.N, d->n_static + g, m, D.var[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term,
+            int rc = lpi_host_solve_batch_warm(g == 0 ? D.N : D.Nf, d->n_static + g, m, D.var[g], D.B, D.x0, D.u0, g == 0 ? D.xref : D.xref_fix, D.A[g], D.b[g], D.Ts, D.term,
                                                hp, D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr,
                                                D.warm ? D.wz[g] : nullptr, D.warm ? D.wuse[g] : nullptr, warm_mu);
             if (rc) return rc;
             if (g == 0) continue;
             for (int b = 0; b < D.B; ++b) make_retry(D, g, b);
-            rc = lpi_host_solve_batch_warm(D.N, d->n_static + g, m, D.var8[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term,
+            rc = lpi_host_solve_batch_warm(D.Nf, d->n_static + g, m, D.var8[g], D.B, D.x0, D.u0, D.xref_fix, D.A[g], D.b[g], D.Ts, D.term,
                                            hp, D.xopt[g], D.uopt[g], D.ts[g], D.status8[g], D.iters8[g], nullptr,
                                            D.warm ? D.wz[g] : nullptr, D.warm ? D.wuse[g] : nullptr, warm_mu);
             if (rc) return rc;

@@ -155,3 +155,27 @@ def test_long_horizon_rollouts_take_the_lockstep_path():
     assert np.array_equal(out["steps"], ref["steps"]) and out["steps"].sum() >= 8
     assert np.array_equal(out["variant"], ref["variant"])
     np.testing.assert_allclose(out["x_closed"], ref["x_closed"], rtol=0, atol=1e-6)
+
+
+def test_fixed_time_horizon_twice_the_free_time_one_on_the_device():
+    """H5 with resampling ratio 2 (N_free = 5, N_fix = 10) on the GPU: the fused kernel and the lock-step launches equal the
+    CPU build of the same harness + structured core, which tests/test_rollout_core.py holds against the Python mirror"""
+    from oracle import c_oracle
+    from tests import native_build
+    settings = [problemSetting("demo8")] + [make_world_c5(i, n_dyn=1) for i in range(7)]
+    ref = None
+    for mode in ("fused", "lockstep"):
+        groups = {}
+        for s in settings:
+            groups.setdefault((tuple(int(v) for v in s.static_vObs), len(s.dyn_obs_info)), []).append(s)
+        for key, ss in groups.items():
+            w = pack_worlds(copy.deepcopy(ss))
+            dr = DeviceRollouts(w, N=5, N_fix=10)
+            dr.set_mode(mode)
+            o = {k: v.cpu().numpy() for k, v in dr.run(6).read().items()}
+            h = native_build.rollout_run(pack_worlds(copy.deepcopy(ss)), 5, c_oracle.default_params(), 6, N_fix=10)
+            assert o["x_openloop"].shape[3] == 11
+            assert np.array_equal(o["steps"], h["steps"]) and np.array_equal(o["variant"][:, :6], h["variant"][:, :6])
+            assert (o["variant"] >= 6).any() or len(ss) == 1
+            np.testing.assert_allclose(o["x_closed"][:, :7], h["x_closed"][:, :7], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(o["x_openloop"][:, :6], h["x_openloop"][:, :6], rtol=0, atol=1e-6)

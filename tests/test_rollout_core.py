@@ -105,3 +105,38 @@ def test_history_export_matches_the_mirror_lists():
             for va, vb in zip(a, b):
                 np.testing.assert_allclose(np.array(va[:5]), np.array(vb[:5]), rtol=0, atol=1e-9)
                 assert va[5] == vb[5]
+
+
+def test_fixed_time_horizon_twice_the_free_time_one():
+    """H5 with a resampling ratio of 2 (N_free = 5, N_fix = 10; reference src/closed_loop.py:570-587: the first N_free
+    segments of the window become int(N_fix/N_free) points each).  The device harness follows the Python mirror step by step;
+    the mirror's update_path is the fixture-pinned restatement of the reference's.  (6/12 cannot run in the reference: its
+    shift-in of the previous plan, :363-364, reads column 7 of a 7-column free-time plan -- IndexError.)"""
+    settings = [problemSetting("demo8")]
+    w = pack_worlds(copy.deepcopy(settings))
+    out = native_build.rollout_run(w, 5, c_oracle.default_params(), 8, N_fix=10)
+    solver = native_build.LpiObca()
+    cl = closedLoop(copy.deepcopy(settings[0]), solver=solver)
+    cl.N_free, cl.N_fix = 5, 10
+    steps = 0
+    while steps < 8 and not cl.goal_reached():
+        steps += 1
+        if not cl.step():
+            break
+    assert out["steps"][0] == cl.k and cl.k >= 3
+    var = out["variant"][0, :cl.k].tolist()
+    assert 4 in var and (6 in var or 8 in var)                       # both problem sizes were solved
+    j = 0
+    for k in range(cl.k):
+        v = var[k]
+        c = solver.calls[j]
+        if v == 8:
+            j += 1
+            c = solver.calls[j]
+        assert c["variant"] == v
+        n1 = c["xref"].shape[1]
+        assert n1 == (6 if v == 4 else 11)
+        np.testing.assert_allclose(out["xref"][0, k][:, :n1], c["xref"], rtol=0, atol=TOL)
+        j += 1
+    np.testing.assert_allclose(out["x_closed"][0, :cl.k + 1], np.asarray(cl.x_closed)[:cl.k + 1], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out["T_closed"][0, :cl.k], np.asarray(cl.T_closed), rtol=0, atol=1e-7)

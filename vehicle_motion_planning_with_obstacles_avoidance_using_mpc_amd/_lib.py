@@ -35,7 +35,7 @@ class ObcaParams(ctypes.Structure):
 class ObcaRolloutDims(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int32), ("n_static", ctypes.c_int32), ("m_static", ctypes.c_int32 * OBCA_MAX_OBST),
                 ("n_dyn", ctypes.c_int32), ("path_max", ctypes.c_int32), ("batch", ctypes.c_int32),
-                ("max_steps", ctypes.c_int32), ("device", ctypes.c_int32)]
+                ("max_steps", ctypes.c_int32), ("device", ctypes.c_int32), ("N_fix", ctypes.c_int32)]
 
 
 EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",

@@ -90,6 +90,10 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     if (!d || d->N < 1 || d->N > 127 || d->n_static < 1 || d->n_dyn < 0 || d->n_dyn > OBCA_MAX_DYN ||
         d->n_static + d->n_dyn > OBCA_MAX_OBST || d->path_max < 2 || d->batch < 1 || d->max_steps < 1)
         return OBCA_E_INVAL;
+    {   // fixed-time horizon: a multiple of N whose shift-in (N_fix - 5 columns of the previous plan) a free-time plan covers
+        const int nf = d->N_fix > 0 ? d->N_fix : d->N;
+        if (nf < d->N || nf % d->N != 0 || nf > 127 || (nf > d->N && (nf - 5 > d->N || d->N > 31))) return OBCA_E_INVAL;
+    }
     for (int i = 0; i < d->n_static; ++i)
         if (d->m_static[i] < 1 || d->m_static[i] > OBCA_MAX_EDGES) return OBCA_E_INVAL;
     obca_rollouts* r = new (std::nothrow) obca_rollouts();
@@ -103,30 +107,32 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     rollout::Dev& D = r->D;
     memset(&D, 0, sizeof(D));
     D.B = d->batch; D.N = d->N; D.n_static = d->n_static; D.n_dyn = d->n_dyn; D.P = d->path_max; D.S = d->max_steps;
+    D.Nf = d->N_fix > 0 ? d->N_fix : d->N;
+    D.Nm = D.Nf > D.N ? D.Nf : D.N;
     D.Ms = 0;
     for (int i = 0; i < d->n_static; ++i) D.Ms += d->m_static[i];
-    const size_t B = d->batch, N1 = d->N + 1, N = d->N, S = d->max_steps, nd = d->n_dyn;
+    const size_t B = d->batch, N1 = d->N + 1, S = d->max_steps, nd = d->n_dyn, Nm1 = D.Nm + 1, Nf1 = D.Nf + 1;
     bool ok = true;
     ok = ok && dev_alloc(r, r->goal, B * 2) && dev_alloc(r, r->path, B * 3 * D.P) && dev_alloc(r, r->path_len, B) &&
          dev_alloc(r, r->As, B * D.Ms * 2) && dev_alloc(r, r->bs, B * D.Ms);
     D.goal = r->goal; D.path = r->path; D.path_len = r->path_len; D.As = r->As; D.bs = r->bs;
     ok = ok && dev_alloc(r, D.x0, B * 3) && dev_alloc(r, D.u0, B * 2) && dev_alloc(r, D.Ts, B) && dev_alloc(r, D.Ts_opt, B) &&
-         dev_alloc(r, D.xprev, B * 3 * N1) && dev_alloc(r, D.dyn, B * nd * rollout::DYN_W) && dev_alloc(r, D.k, B) &&
-         dev_alloc(r, D.flags, B) && dev_alloc(r, D.sel, B) && dev_alloc(r, D.xref, B * 3 * N1) && dev_alloc(r, D.term, B * 3);
+         dev_alloc(r, D.xprev, B * 3 * Nm1) && dev_alloc(r, D.dyn, B * nd * rollout::DYN_W) && dev_alloc(r, D.k, B) &&
+         dev_alloc(r, D.flags, B) && dev_alloc(r, D.sel, B) && dev_alloc(r, D.xref, B * 3 * N1) && dev_alloc(r, D.xref_fix, B * 3 * Nf1) && dev_alloc(r, D.term, B * 3);
     ok = ok && dev_alloc(r, D.xc, B * (S + 1) * 3) && dev_alloc(r, D.uc, B * S * 2) && dev_alloc(r, D.Tc, B * S) &&
-         dev_alloc(r, D.xol, B * S * 3 * N1) && dev_alloc(r, D.dh, B * S * nd * 4) && dev_alloc(r, D.vh, B * S) &&
+         dev_alloc(r, D.xol, B * S * 3 * Nm1) && dev_alloc(r, D.dh, B * S * nd * 4) && dev_alloc(r, D.vh, B * S) &&
          dev_alloc(r, D.ih, B * S) && dev_alloc(r, D.sh, B * S);
     int rc = ok ? OBCA_OK : OBCA_E_NOMEM;
     for (int g = 0; g <= d->n_dyn && rc == OBCA_OK; ++g) {
-        const size_t Mg = D.Ms + 4 * g;
-        ok = dev_alloc(r, D.var[g], B) && dev_alloc(r, D.var8[g], B) && dev_alloc(r, D.A[g], B * N1 * Mg * 2) &&
-             dev_alloc(r, D.b[g], B * N1 * Mg) && dev_alloc(r, D.xopt[g], B * 3 * N1) && dev_alloc(r, D.uopt[g], B * 2 * N) &&
+        const size_t Mg = D.Ms + 4 * g, Ng = g == 0 ? D.N : D.Nf, Ng1 = Ng + 1;     // group 0: free-time horizon; others: N_fix
+        ok = dev_alloc(r, D.var[g], B) && dev_alloc(r, D.var8[g], B) && dev_alloc(r, D.A[g], B * Ng1 * Mg * 2) &&
+             dev_alloc(r, D.b[g], B * Ng1 * Mg) && dev_alloc(r, D.xopt[g], B * 3 * Ng1) && dev_alloc(r, D.uopt[g], B * 2 * Ng) &&
              dev_alloc(r, D.ts[g], B) && dev_alloc(r, D.status[g], B) && dev_alloc(r, D.iters[g], B) &&
              dev_alloc(r, D.status8[g], B) && dev_alloc(r, D.iters8[g], B);
         if (!ok) { rc = OBCA_E_NOMEM; break; }
         obca_dims sd;
         memset(&sd, 0, sizeof(sd));
-        sd.N = d->N; sd.n_obs = d->n_static + g; sd.max_batch = d->batch; sd.device = d->device;
+        sd.N = (int32_t)Ng; sd.n_obs = d->n_static + g; sd.max_batch = d->batch; sd.device = d->device;
         for (int i = 0; i < d->n_static; ++i) sd.m[i] = d->m_static[i];
         for (int i = 0; i < g; ++i) sd.m[d->n_static + i] = 4;
         rc = obca_create(&sd, &r->solver[g]);
@@ -153,7 +159,7 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
     if (!guard.ok) return OBCA_E_HIP;
     hipStream_t s = (hipStream_t)hip_stream;
     rollout::Dev& D = r->D;
-    const size_t B = D.B, N1 = D.N + 1, S = D.S, nd = D.n_dyn;
+    const size_t B = D.B, N1 = D.Nm + 1, S = D.S, nd = D.n_dyn;
     bool ok = hipMemcpyAsync(r->goal, goal, sizeof(double) * B * 2, hipMemcpyDeviceToDevice, s) == hipSuccess &&
               hipMemcpyAsync(r->path, path, sizeof(double) * B * 3 * D.P, hipMemcpyDeviceToDevice, s) == hipSuccess &&
               hipMemcpyAsync(r->path_len, path_len, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, s) == hipSuccess &&
@@ -187,7 +193,7 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
         for (int a = 0; a < 2; ++a) {
             int64_t lds = 0;
             int wave_ok = 0;
-            const int rc = obca_internal_fill_launch(r->solver[g], a ? D.var8[g] : D.var[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g],
+            const int rc = obca_internal_fill_launch(r->solver[g], a ? D.var8[g] : D.var[g], D.B, D.x0, D.u0, g == 0 ? D.xref : D.xref_fix, D.A[g], D.b[g],
                                                      D.Ts, D.term, &r->params, D.xopt[g], D.uopt[g], D.ts[g],
                                                      a ? D.status8[g] : D.status[g], a ? D.iters8[g] : D.iters[g], nullptr,
                                                      &r->hL[g + a * rollout::MAX_GROUPS], &lds, &wave_ok);
@@ -228,12 +234,12 @@ extern "C" int obca_rollouts_step(obca_rollouts* r, void* hip_stream) {
         // group 0 (obca_mpc4, static obstacles) stays on the caller's stream; the fixed-time groups run beside it
         hipStream_t gs = g == 0 ? s : r->gstream[g];
         if (g > 0 && hipStreamWaitEvent(gs, r->fork, 0) != hipSuccess) return OBCA_E_HIP;
-        int rc = obca_solve_batch(r->solver[g], D.var[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term, &r->params,
+        int rc = obca_solve_batch(r->solver[g], D.var[g], D.B, D.x0, D.u0, g == 0 ? D.xref : D.xref_fix, D.A[g], D.b[g], D.Ts, D.term, &r->params,
                                   D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr, (void*)gs);
         if (rc != OBCA_OK) return rc;
         if (g == 0) continue;
         hipLaunchKernelGGL(rollout_retry_kernel, grid, block, 0, gs, D, g);
-        rc = obca_solve_batch(r->solver[g], D.var8[g], D.B, D.x0, D.u0, D.xref, D.A[g], D.b[g], D.Ts, D.term, &r->params,
+        rc = obca_solve_batch(r->solver[g], D.var8[g], D.B, D.x0, D.u0, D.xref_fix, D.A[g], D.b[g], D.Ts, D.term, &r->params,
                               D.xopt[g], D.uopt[g], D.ts[g], D.status8[g], D.iters8[g], nullptr, (void*)gs);
         if (rc != OBCA_OK) return rc;
         if (hipEventRecord(r->join[g], gs) != hipSuccess || hipStreamWaitEvent(s, r->join[g], 0) != hipSuccess) return OBCA_E_HIP;
@@ -252,7 +258,7 @@ extern "C" int obca_rollouts_set_warm_start(obca_rollouts* r, int enable, double
         for (int g = 0; g <= D.n_dyn; ++g) {
             obca_dims sd;
             memset(&sd, 0, sizeof(sd));
-            sd.N = D.N; sd.n_obs = D.n_static + g; sd.max_batch = D.B; sd.device = r->dims.device;
+            sd.N = g == 0 ? D.N : D.Nf; sd.n_obs = D.n_static + g; sd.max_batch = D.B; sd.device = r->dims.device;
             for (int i = 0; i < D.n_static; ++i) sd.m[i] = r->dims.m_static[i];
             for (int i = 0; i < g; ++i) sd.m[D.n_static + i] = 4;
             const int64_t n = obca_primal_size(&sd);
@@ -304,7 +310,7 @@ extern "C" int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_
     if (!guard.ok) return OBCA_E_HIP;
     hipStream_t s = (hipStream_t)hip_stream;
     const rollout::Dev& D = r->D;
-    const size_t B = D.B, N1 = D.N + 1, S = D.S, nd = D.n_dyn;
+    const size_t B = D.B, N1 = D.Nm + 1, S = D.S, nd = D.n_dyn;
     auto cp = [&](void* dst, const void* src, size_t bytes) {
         return !dst || bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
     };

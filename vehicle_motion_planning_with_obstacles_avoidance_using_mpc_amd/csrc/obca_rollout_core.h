@@ -2,7 +2,8 @@
 //
 // Restates the body of the reference's receding-horizon loop (src/closed_loop.py:345-432) for a batch laid out
 // as structure-of-arrays in HBM: update_obstacle (:445-486), sensor (:591-629), update_reference_trajectory
-// (:502-528), the fixed-time reference preparation (:360-374, update_path(allAviable=1) :570-587, ratio 1),
+// (:502-528), the fixed-time reference preparation (:360-374, update_path(allAviable=1) :570-587 with its
+// resampling ratio int(N_fix / N_free)),
 // rebuild_lObs (src/demo_setting.py:457-473) + obstacle_H_Represent (src/model_obstacle.py:37-102) for the
 // moving rectangles, the dispatch mpc4 / mpc6 -> mpc8 (:380-398) and the state advance (:400-432).
 // Compiles for the device (obca_rollout.hip) and for the host (tests/native/rollout_host.cpp); floating-point
@@ -34,6 +35,7 @@ constexpr int MAX_GROUPS = OBCA_MAX_DYN + 1;   // group g = number of sensed mov
 
 struct Dev {
     int32_t B, N, n_static, Ms, n_dyn, P, S;
+    int32_t Nf, Nm;                 // horizon of the fixed-time problem (N_fix) and max(N, Nf): stride of xprev / xol
     double sense_dis, ego_l, ego_w;
     // per-rollout constants
     const double *goal, *path, *As, *bs;
@@ -41,8 +43,8 @@ struct Dev {
     // per-rollout state (H0: src/closed_loop.py:18-111)
     double *x0, *u0, *Ts, *Ts_opt, *xprev, *dyn;
     int32_t *k, *flags, *sel;
-    // solver inputs shared by all groups
-    double *xref, *term;
+    // solver inputs: reference window of the free-time problem [B,3,N+1] / of the fixed-time problems [B,3,Nf+1]
+    double *xref, *xref_fix, *term;
     // per group
     int32_t *var[MAX_GROUPS], *var8[MAX_GROUPS];
     double *A[MAX_GROUPS], *b[MAX_GROUPS];
@@ -100,7 +102,7 @@ RO_FN void reset(const Dev& D, int b, const double* start, const double* dyn0, d
     D.Ts[b] = Ts0; D.Ts_opt[b] = Ts0;
     D.k[b] = 0; D.sel[b] = 0;
     for (int t = 0; t < D.n_dyn * DYN_W; ++t) D.dyn[(size_t)b * D.n_dyn * DYN_W + t] = dyn0[(size_t)b * D.n_dyn * DYN_W + t];
-    for (int t = 0; t < 3 * (D.N + 1); ++t) D.xprev[(size_t)b * 3 * (D.N + 1) + t] = 0.0;
+    for (int t = 0; t < 3 * (D.Nm + 1); ++t) D.xprev[(size_t)b * 3 * (D.Nm + 1) + t] = 0.0;
     for (int j = 0; j < 3; ++j) D.xc[((size_t)b * (D.S + 1)) * 3 + j] = start[3 * b + j];
     D.flags[b] = at_goal(D, b) ? OBCA_DONE_GOAL : OBCA_RUN;
 }
@@ -152,8 +154,11 @@ RO_FN void prepare(const Dev& D, int b) {
     }
     const bool fixtime = ns > 0;
 
-    // H4 update_reference_trajectory: window from the first strict minimum of the squared distance
-    double* xr = D.xref + (size_t)b * 3 * N1;
+    // H4 update_reference_trajectory: window from the first strict minimum of the squared distance; N+1 points for the
+    // free-time problem, N_fix+1 for the fixed-time one (:354, :361)
+    const bool free_step = (k == 0 || !fixtime);
+    const int Nw = free_step ? N : D.Nf, Nw1 = Nw + 1;
+    double* xr = free_step ? D.xref + (size_t)b * 3 * N1 : D.xref_fix + (size_t)b * 3 * Nw1;
     {
         const double* p = D.path + (size_t)b * 3 * D.P;
         const int len = D.path_len[b];
@@ -164,15 +169,15 @@ RO_FN void prepare(const Dev& D, int b) {
             const double d = dx * dx + dy * dy;
             if (d < best) { best = d; i0 = i; }
         }
-        for (int t = 0; t < N1; ++t) {
+        for (int t = 0; t < Nw1; ++t) {
             const int i = (i0 + t < len - 1) ? i0 + t : len - 1;
-            for (int j = 0; j < 3; ++j) xr[j * N1 + t] = p[j * D.P + i];
+            for (int j = 0; j < 3; ++j) xr[j * Nw1 + t] = p[j * D.P + i];
         }
     }
 
     const double* As = D.As + (size_t)b * D.Ms * 2;
     const double* bs = D.bs + (size_t)b * D.Ms;
-    if (k == 0 || !fixtime) {                                            // H6: obca_mpc4 on the static obstacles
+    if (free_step) {                                                     // H6: obca_mpc4 on the static obstacles
         double* Ag = D.A[0] + (size_t)b * N1 * D.Ms * 2;
         double* bg = D.b[0] + (size_t)b * N1 * D.Ms;
         for (int kk = 0; kk < N1; ++kk) {
@@ -185,22 +190,40 @@ RO_FN void prepare(const Dev& D, int b) {
         return;
     }
 
-    // H5 fixed-time reference: shifted previous plan in front, yaw recomputed, step rescaled, Ts overwritten (q7)
-    const double* xp = D.xprev + (size_t)b * 3 * N1;
-    for (int i = 0; i < N - 5; ++i)
-        for (int j = 0; j < 3; ++j) xr[j * N1 + i] = xp[j * N1 + i + 1];
-    for (int i = 0; i < N; ++i) xr[2 * N1 + i] = atan2(xr[N1 + i + 1] - xr[N1 + i], xr[i + 1] - xr[i]);
-    xr[2 * N1 + N] = xr[2 * N1 + N - 1];
-    Ts_opt = ((double)N * Ts_opt) / (double)N;
+    // H5 fixed-time reference: shifted previous plan in front (:363-364), then update_path(allAviable=1) (:570-587): the first
+    // N_free segments of the window are resampled into int(N_fix/N_free) points each (numpy.linspace without the end
+    // point: start + j * ((stop - start) / ratio)), the window's LAST point closes the list, yaw recomputed, step
+    // rescaled, Ts overwritten (q7).  N_fix is a multiple of N_free here, so the list has N_fix + 1 points again.
+    const int Nf = D.Nf, Nf1 = Nf + 1, ratio = Nf / N;
+    const double* xp = D.xprev + (size_t)b * 3 * (D.Nm + 1);
+    for (int i = 0; i < Nf - 5; ++i)
+        for (int j = 0; j < 3; ++j) xr[j * Nf1 + i] = xp[j * (D.Nm + 1) + i + 1];
+    if (ratio > 1) {
+        const double lastx = xr[Nf], lasty = xr[Nf1 + Nf];
+        // in place, back to front would overwrite sources: the sources are columns 0..N, the targets 0..N*ratio
+        double sx[32], sy[32];                    // N_free <= 31 when the ratio exceeds 1 (checked by obca_rollouts_create)
+        for (int i = 0; i <= N; ++i) { sx[i] = xr[i]; sy[i] = xr[Nf1 + i]; }
+        for (int i = 0; i < N; ++i) {
+            const double stx = (sx[i + 1] - sx[i]) / (double)ratio, sty = (sy[i + 1] - sy[i]) / (double)ratio;
+            for (int j = 0; j < ratio; ++j) {
+                xr[i * ratio + j] = (double)j * stx + sx[i];
+                xr[Nf1 + i * ratio + j] = (double)j * sty + sy[i];
+            }
+        }
+        xr[Nf] = lastx; xr[Nf1 + Nf] = lasty;
+    }
+    for (int i = 0; i < Nf; ++i) xr[2 * Nf1 + i] = atan2(xr[Nf1 + i + 1] - xr[Nf1 + i], xr[i + 1] - xr[i]);
+    xr[2 * Nf1 + Nf] = xr[2 * Nf1 + Nf - 1];
+    Ts_opt = ((double)N * Ts_opt) / (double)Nf;
     D.Ts_opt[b] = Ts_opt;
     D.Ts[b] = Ts_opt;
     D.term[3 * b] = x0[0] + 5; D.term[3 * b + 1] = 1.0; D.term[3 * b + 2] = 9.0;      // :371
 
     // S5/S4: static rows, then the first ns PRESENT rectangles (q8) moved with the SENSED obstacles' velocities
     const int g = ns, Mg = D.Ms + 4 * ns;
-    double* Ag = D.A[g] + (size_t)b * N1 * Mg * 2;
-    double* bg = D.b[g] + (size_t)b * N1 * Mg;
-    for (int kk = 0; kk < N1; ++kk) {
+    double* Ag = D.A[g] + (size_t)b * Nf1 * Mg * 2;
+    double* bg = D.b[g] + (size_t)b * Nf1 * Mg;
+    for (int kk = 0; kk < Nf1; ++kk) {
         double* Ak = Ag + (size_t)kk * Mg * 2;
         double* bk = bg + (size_t)kk * Mg;
         for (int q = 0; q < 2 * D.Ms; ++q) Ak[q] = As[q];
@@ -233,7 +256,8 @@ RO_FN void make_retry(const Dev& D, int g, int b) {
 RO_FN void finish(const Dev& D, int b) {
     RO_EXACT
     if (D.flags[b] != OBCA_RUN) return;
-    const int N = D.N, N1 = N + 1, g = D.sel[b], k = D.k[b];
+    const int g = D.sel[b], k = D.k[b];
+    const int N = (g == 0) ? D.N : D.Nf, N1 = N + 1, Nm1 = D.Nm + 1;         // horizon of the problem this step solved
     int st = D.status[g][b], it = D.iters[g][b], variant = (g == 0) ? 4 : 6;
     if (g > 0 && D.var8[g][b] == 8) { st = D.status8[g][b]; it += D.iters8[g][b]; variant = 8; }
     D.vh[(size_t)b * D.S + k] = variant;
@@ -242,10 +266,12 @@ RO_FN void finish(const Dev& D, int b) {
     if (!status_feasible(st)) { D.flags[b] = OBCA_DONE_FAILED; return; }
     const double* xo = D.xopt[g] + (size_t)b * 3 * N1;
     const double* uo = D.uopt[g] + (size_t)b * 2 * N;
-    for (int t = 0; t < 3 * N1; ++t) {
-        D.xprev[(size_t)b * 3 * N1 + t] = xo[t];
-        D.xol[((size_t)b * D.S + k) * 3 * N1 + t] = xo[t];
-    }
+    for (int j = 0; j < 3; ++j)
+        for (int t = 0; t < Nm1; ++t) {
+            const double v = t < N1 ? xo[j * N1 + t] : 0.0;
+            D.xprev[(size_t)b * 3 * Nm1 + j * Nm1 + t] = v;
+            D.xol[((size_t)b * D.S + k) * 3 * Nm1 + j * Nm1 + t] = v;
+        }
     for (int j = 0; j < 2; ++j) {
         D.u0[2 * b + j] = uo[j * N];
         D.uc[((size_t)b * D.S + k) * 2 + j] = uo[j * N];

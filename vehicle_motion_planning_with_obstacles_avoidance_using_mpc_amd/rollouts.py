@@ -103,9 +103,10 @@ def pack_worlds(settings, path_max=None, planner="host"):
     return w
 
 
-def rollout_dims(w, N, max_steps, device=0):
+def rollout_dims(w, N, max_steps, device=0, N_fix=None):
     d = _lib.ObcaRolloutDims()
     d.N, d.n_static, d.n_dyn = int(N), len(w.m_static), int(w.n_dyn)
+    d.N_fix = int(N if N_fix is None else N_fix)
     for i, v in enumerate(w.m_static):
         d.m_static[i] = int(v)
     d.path_max, d.batch, d.max_steps, d.device = int(w.path.shape[2]), int(w.batch), int(max_steps), int(device)
@@ -162,8 +163,9 @@ class DeviceRollouts:
     """B rollouts on one GPU.  ``step()`` enqueues one receding-horizon step of every running rollout;
     ``run()`` all of them; ``read()`` returns state and history (torch tensors on the device)."""
 
-    def __init__(self, worlds, N=6, params=None, Ts0=0.1, max_steps=30, device=None, warm_start=None):
-        """N: horizon of both problems (the reference's committed default is N_free = N_fix = 6, src/closed_loop.py:84,91).
+    def __init__(self, worlds, N=6, params=None, Ts0=0.1, max_steps=30, device=None, warm_start=None, N_fix=None):
+        """N: horizon of the free-time problem, N_fix (default N): of the fixed-time problems (the reference's committed
+        default is N_free = N_fix = 6, src/closed_loop.py:84,91; N_fix must be a multiple of N with N_fix - 5 <= N).
         params: None = the reference's controller constants with the position box of the worlds (setting.xL / xU).
         warm_start: None = the reference's cold start of every solve; a float mu_init = start each step whose
         problem shape equals the previous step's from the shifted previous plan (NOT reference behaviour)."""
@@ -175,9 +177,10 @@ class DeviceRollouts:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.w = worlds if isinstance(worlds, PackedWorlds) else pack_worlds(worlds)
         self.N, self.max_steps, self.Ts0 = int(N), int(max_steps), float(Ts0)
+        self.N_fix = self.N if N_fix is None else int(N_fix)
         self.params = params or SolverParams(xL=getattr(self.w, "xL", (0.0, 0.0)), xU=getattr(self.w, "xU", (39.0, 10.0)))
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self._dims = rollout_dims(self.w, N, max_steps, dev_index)
+        self._dims = rollout_dims(self.w, N, max_steps, dev_index, self.N_fix)
         h = ctypes.c_void_p()
         _lib.check(self.lib.obca_rollouts_create(ctypes.byref(self._dims), ctypes.byref(h)))
         self._h = h
@@ -219,7 +222,7 @@ class DeviceRollouts:
         _lib.check(self.lib.obca_rollouts_set_mode(self._h, self.mode))
 
     def read(self):
-        t, B, S, N1, nd = self.torch, self.w.batch, self.max_steps, self.N + 1, self.w.n_dyn
+        t, B, S, N1, nd = self.torch, self.w.batch, self.max_steps, max(self.N, self.N_fix) + 1, self.w.n_dyn
         f = lambda *shape: t.empty(*shape, dtype=t.float64, device=self.device)
         i = lambda *shape: t.empty(*shape, dtype=t.int32, device=self.device)
         out = {"x_closed": f(B, S + 1, 3), "u_closed": f(B, S, 2), "T_closed": f(B, S), "x_openloop": f(B, S, 3, N1),
@@ -241,7 +244,7 @@ class DeviceRollouts:
             pass
 
 
-def reference_lists(out, worlds, i):
+def reference_lists(out, worlds, i, N_free=None):
     """History of rollout ``i`` in the form the reference's ``closedLoop`` keeps for its plot routine
     (src/closed_loop.py:416-441, src/draw.py:333-456): ``x_openLoop`` list of (N+1,3) arrays, ``x_closed`` list of
     poses, ``u_closed`` list of inputs, ``Ts_opt`` list, ``dyn_loc`` list (per step) of the present moving
@@ -250,7 +253,11 @@ def reference_lists(out, worlds, i):
     g = lambda k: np.asarray(out[k].cpu() if hasattr(out[k], "cpu") else out[k])
     k = int(g("steps")[i])
     tried = int((g("variant")[i] > 0).sum())              # a failed last step still updated the obstacles
-    res = {"x_openLoop": [g("x_openloop")[i, j].T.copy() for j in range(k)],
+    var = g("variant")[i]
+    n_cols = g("x_openloop").shape[3]
+    n_free = N_free                       # only needed when N_fix > N_free: free-time plans fill N_free + 1 of the columns
+    cols = lambda j: (n_free + 1) if (n_free is not None and var[j] == 4) else n_cols
+    res = {"x_openLoop": [g("x_openloop")[i, j][:, :cols(j)].T.copy() for j in range(k)],
            "x_closed": [g("x_closed")[i, j].copy() for j in range(k + 1)],
            "u_closed": [g("u_closed")[i, j].copy() for j in range(k)],
            "Ts_opt": [float(v) for v in g("T_closed")[i, :k]],
