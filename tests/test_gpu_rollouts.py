@@ -162,6 +162,9 @@ def test_fixed_time_horizon_twice_the_free_time_one_on_the_device():
     CPU build of the same harness + structured core, which tests/test_rollout_core.py holds against the Python mirror"""
     from oracle import c_oracle
     from tests import native_build
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
     settings = [problemSetting("demo8")] + [make_world_c5(i, n_dyn=1) for i in range(7)]
     ref = None
     for mode in ("fused", "lockstep"):
