@@ -252,6 +252,13 @@ int obca_astar_batch(const uint8_t* grid, int32_t B, int32_t rows, int32_t cols,
                      const int32_t* goal, const double* yaw9, int32_t path_max, double* path, int32_t* path_len,
                      void* workspace, int64_t workspace_bytes, void* hip_stream);
 
+/* Occupancy grids of B worlds on the device -- the reference's mapModel.shape2grid (src/model_map.py:21-56; vertex
+ * re-ordering :88-101 and the division by the resolution :58-71 included): boxes [B,K,4] = (xmin, ymin, xmax, ymax) of each
+ * obstacle polygon in world units (an entry with xmin > xmax or NaN is padding), grid [B,rows,cols] uint8 (1 = occupied),
+ * rows = int((map_y - 1)/resolution) + 1, cols likewise (src/model_map.py:17).  The grid is what obca_astar_batch takes. */
+int obca_rasterise_batch(const double* boxes, int32_t B, int32_t K, double resolution, int32_t rows, int32_t cols,
+                         uint8_t* grid, void* hip_stream);
+
 const char* obca_strerror(int code);
 const char* obca_version(void);
 

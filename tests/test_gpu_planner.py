@@ -84,3 +84,28 @@ def test_planner_throughput_smoke():
     dt = time.time() - t
     print("4096 A* searches on an 11x40 grid: %.1f ms" % (dt * 1e3))
     assert int((plen > 0).sum()) == 4096 and dt < 20.0
+
+
+def test_device_rasteriser_equals_the_reference_grids(harness_golden):
+    """row N2, second half: mapModel.shape2grid (reference src/model_map.py:21-101) for a batch of worlds in one launch,
+    bit-exact against the host mirror (which fixture F9 pins to the reference's org_gridMap of demo1/8/9/10) on the demo
+    worlds and on 256 Monte-Carlo worlds; the grids then feed the batched A* without leaving the device"""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.planner import plan_batch, rasterise_batch
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
+    for demo in ("demo1", "demo8", "demo9", "demo10"):
+        s = problemSetting(demo)
+        g = rasterise_batch([s.static_gridlObs], s.map_size, s.resolution).cpu().numpy()[0]
+        assert g.shape == np.asarray(s.org_gridMap).shape and np.array_equal(g, np.asarray(s.org_gridMap).astype(np.uint8)), demo
+    worlds = [make_world_c5(i, n_dyn=0) for i in range(256)]
+    for w in worlds:
+        w.ref_path = None                                   # plan on the device instead of using the generator's path
+    grids = rasterise_batch([w.static_gridlObs for w in worlds], worlds[0].map_size, worlds[0].resolution)
+    host = np.stack([np.asarray(w.org_gridMap) for w in worlds]).astype(np.uint8)
+    assert np.array_equal(grids.cpu().numpy(), host)
+    starts = [(w.startPose[1], w.startPose[0]) for w in worlds]
+    goals = [(w.goalPose[1], w.goalPose[0]) for w in worlds]
+    path, plen = plan_batch(grids, starts, goals)           # device grid -> device A*: nothing went through the host
+    p2, l2 = plan_batch(host, starts, goals)
+    assert np.array_equal(plen.cpu().numpy(), l2.cpu().numpy()) and (plen.cpu().numpy() > 0).all()
+    assert np.array_equal(path.cpu().numpy(), p2.cpu().numpy())

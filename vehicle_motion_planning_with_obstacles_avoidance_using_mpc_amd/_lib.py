@@ -42,7 +42,7 @@ EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", 
            "obca_set_profile_buffer", "obca_set_mode", "obca_rollouts_create", "obca_rollouts_destroy",
            "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read", "obca_rollouts_run",
            "obca_rollouts_set_mode", "obca_astar_batch", "obca_astar_workspace_bytes", "obca_primal_size", "obca_set_warm_start",
-           "obca_rollouts_set_warm_start", "obca_dual_size", "obca_set_certificate_buffers")
+           "obca_rollouts_set_warm_start", "obca_dual_size", "obca_set_certificate_buffers", "obca_rasterise_batch")
 
 OBCA_MAX_DYN = 4
 RUN, DONE_GOAL, DONE_CAP, DONE_FAILED = 0, 1, 2, 3
@@ -119,6 +119,8 @@ def load():
     lib.obca_astar_batch.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp,
                                      ctypes.POINTER(ctypes.c_double), ctypes.c_int32, vp, vp, vp, ctypes.c_int64, vp]
     lib.obca_astar_batch.restype = ctypes.c_int
+    lib.obca_rasterise_batch.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, vp, vp]
+    lib.obca_rasterise_batch.restype = ctypes.c_int
     lib.obca_primal_size.argtypes = [ctypes.POINTER(ObcaDims)]
     lib.obca_primal_size.restype = ctypes.c_int64
     lib.obca_set_warm_start.argtypes = [ctypes.c_void_p, vp, vp, ctypes.c_double]

@@ -27,7 +27,39 @@ __global__ void __launch_bounds__(64) astar_kernel(AstarLaunch A) {
                                 A.path + (size_t)b * 3 * A.path_max, A.path_max);
 }
 
+// Occupancy grid of B worlds (reference mapModel.shape2grid, src/model_map.py:21-56, with reOrderVertex :88-101 and
+// world2gridmap :58-71 applied by the caller / here): obstacle k of world b is the axis-aligned bounding box
+// (xmin, ymin, xmax, ymax) of its polygon; cells x .. x + int(xmax/res - xmin/res), y .. y + int(ymax/res - ymin/res) are
+// set, x = int(xmin/res), y = int(ymin/res) -- the reference's truncations.  One thread per cell: byte work, coalesced.
+__global__ void __launch_bounds__(256) rasterise_kernel(const double* __restrict__ boxes, int B, int K, double res, int rows,
+                                                        int cols, uint8_t* __restrict__ grid) {
+    const size_t cells = (size_t)rows * cols;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * cells) return;
+    const int b = (int)(t / cells);
+    const int cell = (int)(t - (size_t)b * cells), r = cell / cols, c = cell - r * cols;
+    uint8_t occ = 0;
+    for (int k = 0; k < K; ++k) {
+        const double* q = boxes + ((size_t)b * K + k) * 4;
+        const double xmin = q[0] / res, ymin = q[1] / res, xmax = q[2] / res, ymax = q[3] / res;
+        if (!(xmin <= xmax) || !(ymin <= ymax)) continue;                   // padding entry (NaN or inverted box)
+        const int x = (int)xmin, y = (int)ymin, xl = (int)(xmax - xmin) + 1, yl = (int)(ymax - ymin) + 1;
+        if (c >= x && c < x + xl && r >= y && r < y + yl) occ = 1;
+    }
+    grid[t] = occ;
+}
+
 }  // namespace
+
+extern "C" int obca_rasterise_batch(const double* boxes, int32_t B, int32_t K, double resolution, int32_t rows, int32_t cols,
+                                    uint8_t* grid, void* hip_stream) {
+    if (!boxes || !grid || B < 0 || K < 0 || rows < 1 || cols < 1 || !(resolution > 0.0)) return OBCA_E_INVAL;
+    if (B == 0) return OBCA_OK;
+    const size_t total = (size_t)B * rows * cols;
+    hipLaunchKernelGGL(rasterise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, boxes, B, K,
+                       resolution, rows, cols, grid);
+    return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
+}
 
 extern "C" int64_t obca_astar_workspace_bytes(int32_t B, int32_t rows, int32_t cols) {
     if (B < 0 || rows < 1 || cols < 1 || (int64_t)rows * cols > 65535) return -1;
