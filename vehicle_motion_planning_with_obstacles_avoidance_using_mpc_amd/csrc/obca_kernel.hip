@@ -957,6 +957,38 @@ __device__ __forceinline__ int soft_min_regs(const double* Pl, const double* ql,
     return bad;
 }
 
+// LU of I + Ppp E without pivoting (the pivots are those of I + E^1/2 Ppp E^1/2: all positive iff the elastic dynamics
+// rows leave the value function convex), kept as factors: the sweep never needs the inverse itself, only products of it
+// with a few vectors -- (I + Ppp E)^-1 r by substitution, and its transpose through E (I + Ppp E)^-1 E^-1.
+struct Lu3 { double l10, l20, l21, u01, u02, u12, i0, i1, i2; };
+// (explicit fma chains: the one- and four-wavefront instantiations must round alike, whatever the optimiser would contract)
+__device__ __forceinline__ double dot3(double a0, double b0, double a1, double b1, double a2, double b2) {
+    return fma(a2, b2, fma(a1, b1, a0 * b0));
+}
+__device__ __forceinline__ int lu3_factor(const double* P, int ld, const double* E, Lu3& f) {
+    const double a00 = fma(P[0], E[0], 1.0), a01 = P[1] * E[1], a02 = P[2] * E[2];
+    const double a10 = P[ld] * E[0], a11 = fma(P[ld + 1], E[1], 1.0), a12 = P[ld + 2] * E[2];
+    const double a20 = P[2 * ld] * E[0], a21 = P[2 * ld + 1] * E[1], a22 = fma(P[2 * ld + 2], E[2], 1.0);
+    int bad = !(a00 > 0.0);
+    f.l10 = a10 / a00; f.l20 = a20 / a00;
+    const double b11 = fma(-f.l10, a01, a11), b12 = fma(-f.l10, a02, a12), b21 = fma(-f.l20, a01, a21), b22 = fma(-f.l20, a02, a22);
+    bad |= !(b11 > 0.0);
+    f.l21 = b21 / b11;
+    const double c22 = fma(-f.l21, b12, b22);
+    bad |= !(c22 > 0.0);
+    f.u01 = a01; f.u02 = a02; f.u12 = b12;
+    f.i0 = 1.0 / a00; f.i1 = 1.0 / b11; f.i2 = 1.0 / c22;
+    return bad;
+}
+__device__ __forceinline__ void lu3_solve(const Lu3& f, double r0, double r1, double r2, double& x0, double& x1, double& x2) {
+    r1 = fma(-f.l10, r0, r1);
+    r2 = fma(-f.l20, r0, r2);
+    r2 = fma(-f.l21, r1, r2);
+    x2 = r2 * f.i2;
+    x1 = fma(-f.u12, x2, r1) * f.i1;
+    x0 = fma(-f.u02, x2, fma(-f.u01, x1, r0)) * f.i0;
+}
+
 // entry e = 8 a + b of the stage's [F G] = d xi_{k+1} / d (xi_k, du_k), xi = (dp, du_prev, dT): rows 0-2 the pose
 // update p + h (v cos, v sin, w) (column 5: its T-derivative), rows 3-4 pick du_k, row 5 carries dT.  Only ONE
 // stage's 6 x 8 block is kept in LDS: stage k-1's is written while phase B of stage k runs.
@@ -1014,35 +1046,69 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     RPROF(12)
     for (int k = L.N - 1; k >= 0; --k) {
         // ---- phase A ----------------------------------------------------------------------------------
-        double E[3], gh[3], X[36], qt[6], Mi[9];
+        // Entry (a, b) of Mall = Lall + [F G]' P~ [F G] WITHOUT forming P~ = soft-min of (P, E): with M = (I + Ppp E)^-1,
+        //   P~ f = ( M (Ppp f_p + Ppo f_o) ,  Poo f_o + Pop E M (E^-1 f_p - Ppo f_o) )
+        // (second block through M' = E M E^-1), i.e. one 3x3 LU per lane and two substitutions instead of the explicit
+        // inverse, the 3x6 product M [Ppp Ppo], the symmetrised 6x6 P~ and a 6x6 quadratic form -- same pivots, same inertia test.
+        double E[3], Dv[3], gh[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { E[j] = 1.0 / S.Einv[L.r_dyn + 3 * k + j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
+        for (int j = 0; j < 3; ++j) { Dv[j] = S.Einv[L.r_dyn + 3 * k + j]; E[j] = 1.0 / Dv[j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
         if (NT == 64 || lane < 64) {        // (four wavefronts: the serial sweep is the first wavefront's job alone --
             // the others would only repeat it and compete for the LDS)
-            bad |= soft_min_regs(S.Pk + 36 * (k + 1), S.qk + 6 * (k + 1), E, X, qt, Mi);
+            const double* Pl = S.Pk + 36 * (k + 1);
+            const double* ql = S.qk + 6 * (k + 1);
+            double P[36];
+#pragma unroll
+            for (int i = 0; i < 36; ++i) P[i] = Pl[i];
+            Lu3 lu;
+            bad |= lu3_factor(P, 6, E, lu);
             const int a = lane >> 3, b = lane & 7;
             double fa[6], fb[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) { fa[c] = S.FG[8 * c + a]; fb[c] = S.FG[8 * c + b]; }
+            double w3[3], t3[3], u3[3], yp[3], s2[3], yo[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                w3[i] = dot3(P[6 * i + 3], fb[3], P[6 * i + 4], fb[4], P[6 * i + 5], fb[5]);          // Ppo f_o
+                t3[i] = dot3(P[6 * i], fb[0], P[6 * i + 1], fb[1], P[6 * i + 2], fb[2]) + w3[i];
+                u3[i] = fma(Dv[i], fb[i], -w3[i]);
+            }
+            lu3_solve(lu, t3[0], t3[1], t3[2], yp[0], yp[1], yp[2]);
+            lu3_solve(lu, u3[0], u3[1], u3[2], s2[0], s2[1], s2[2]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                yo[i] = dot3(P[6 * (3 + i) + 3], fb[3], P[6 * (3 + i) + 4], fb[4], P[6 * (3 + i) + 5], fb[5]) +
+                        dot3(P[6 * (3 + i)], E[0] * s2[0], P[6 * (3 + i) + 1], E[1] * s2[1], P[6 * (3 + i) + 2], E[2] * s2[2]);
             double v = S.Lall[64 * k + lane];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double z = 0.0;
-#pragma unroll
-                for (int d = 0; d < 6; ++d) z += X[6 * c + d] * fb[d];
-                v += fa[c] * z;
-            }
+            for (int c = 0; c < 3; ++c) v = fma(fa[3 + c], yo[c], fma(fa[c], yp[c], v));
             S.Mall[lane] = v;
-            if (b == 0) {               // gradient: lall + [F G]'(X f + qt), f = (-ghat, 0, 0, 0)
+            if (b == 0) {               // gradient: lall + [F G]'(q~ - P~ f), f = (ghat, 0):
+                // (q~ - P~ f)_p = M (q_p - Ppp ghat),  (q~ - P~ f)_o = q_o - Pop E M (q_p + E^-1 ghat)
+                double q[6], r1[3], r2[3], z1[3], z2[3];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) q[i] = ql[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    r1[i] = q[i] - dot3(P[6 * i], gh[0], P[6 * i + 1], gh[1], P[6 * i + 2], gh[2]);
+                    r2[i] = fma(Dv[i], gh[i], q[i]);
+                }
+                lu3_solve(lu, r1[0], r1[1], r1[2], z1[0], z1[1], z1[2]);
+                lu3_solve(lu, r2[0], r2[1], r2[2], z2[0], z2[1], z2[2]);
                 double w = S.lall[8 * k + a];
 #pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    w += fa[c] * (qt[c] - (X[6 * c] * gh[0] + X[6 * c + 1] * gh[1] + X[6 * c + 2] * gh[2]));
+                for (int i = 0; i < 3; ++i) {
+                    const double zo = q[3 + i] - dot3(P[6 * (3 + i)], E[0] * z2[0], P[6 * (3 + i) + 1], E[1] * z2[1], P[6 * (3 + i) + 2], E[2] * z2[2]);
+                    w = fma(fa[3 + i], zo, fma(fa[i], z1[i], w));
+                }
                 S.mall[a] = w;
             }
-#pragma unroll
-            for (int c = 0; c < 9; ++c)
-                if (lane == c) S.Mik[9 * k + c] = Mi[c];
+            // the factors, for the forward pass (nine numbers, like the inverse they replace)
+            {
+                const double fsel = lane == 0 ? lu.l10 : lane == 1 ? lu.l20 : lane == 2 ? lu.l21 : lane == 3 ? lu.u01 : lane == 4 ? lu.u02
+                                  : lane == 5 ? lu.u12 : lane == 6 ? lu.i0 : lane == 7 ? lu.i1 : lu.i2;
+                if (lane < 9) S.Mik[9 * k + lane] = fsel;
+            }
         }
         SYNC();
         RPROF(13)
@@ -1078,12 +1144,22 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         if (red_or(bad)) return 1;         // wrong-sign pivot: the attempt is over, no need to finish the sweep
     }
     // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
-    double E0[3], g0[3], X[36], qt[6], Mi0[9];
+    double E0[3], D0[3], g0[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { E0[j] = 1.0 / S.Einv[L.r_init + j]; g0[j] = S.gh[L.r_init + j]; }
+    for (int j = 0; j < 3; ++j) { D0[j] = S.Einv[L.r_init + j]; E0[j] = 1.0 / D0[j]; g0[j] = S.gh[L.r_init + j]; }
+    Lu3 lu0;
+    double s1[3] = {0.0, 0.0, 0.0}, X55 = 1.0, qt5 = 0.0;
     if (NT == 64 || lane < 64) {
-        bad |= soft_min_regs(S.Pk, S.qk, E0, X, qt, Mi0);
-        if (L.free_T && !(X[35] > 0.0)) bad = 1;
+        const double* P0 = S.Pk;
+        const double* q0 = S.qk;
+        bad |= lu3_factor(P0, 6, E0, lu0);
+        // row / column T of P~: M Ppo e_T, and the (T, T) entry; q~_T
+        double zq[3];
+        lu3_solve(lu0, P0[5], P0[11], P0[17], s1[0], s1[1], s1[2]);
+        lu3_solve(lu0, q0[0], q0[1], q0[2], zq[0], zq[1], zq[2]);
+        X55 = P0[35] - dot3(P0[30], E0[0] * s1[0], P0[31], E0[1] * s1[1], P0[32], E0[2] * s1[2]);
+        qt5 = q0[5] - dot3(P0[30], E0[0] * zq[0], P0[31], E0[1] * zq[1], P0[32], E0[2] * zq[2]);
+        if (L.free_T && !(X55 > 0.0)) bad = 1;
     }
     bad = red_or(bad);
     RPROF(15)
@@ -1091,17 +1167,18 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     // ---- forward pass: every lane (of the first wavefront) carries the (tiny) state redundantly, lane 0 stores
     if (NT == 64 || lane < 64) {
     double dT = 0.0;
-    if (L.free_T) dT = -(qt[5] - (X[30] * g0[0] + X[31] * g0[1] + X[32] * g0[2])) / X[35];
+    if (L.free_T) dT = -(qt5 - dot3(s1[0], g0[0], s1[1], g0[1], s1[2], g0[2])) / X55;
     double dp[3], up[2] = {0.0, 0.0};
     {
         const double* P0 = S.Pk;
         const double* q0 = S.qk;
-        const double* Mi = Mi0;
         double t[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) t[a] = -g0[a] - E0[a] * (P0[6 * a + 5] * dT + q0[a]);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) dp[a] = Mi[a] * t[0] + Mi[3 + a] * t[1] + Mi[6 + a] * t[2];   // M' t
+        // dp = M' t = E M (E^-1 t)
+        double m0, m1, m2;
+        lu3_solve(lu0, D0[0] * t[0], D0[1] * t[1], D0[2] * t[2], m0, m1, m2);
+        dp[0] = E0[0] * m0; dp[1] = E0[1] * m1; dp[2] = E0[2] * m2;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
             if (lane == 0) S.dy[L.r_init + a] = -(P0[6 * a] * dp[0] + P0[6 * a + 1] * dp[1] + P0[6 * a + 2] * dp[2] + P0[6 * a + 5] * dT + q0[a]);
@@ -1141,8 +1218,13 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
 #pragma unroll
         for (int a = 0; a < 3; ++a)
             t[a] = ph[a] - (P1[6 * a + 3] * u[0] + P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]) / E[a];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) dn[a] = Mi[a] * t[0] + Mi[3 + a] * t[1] + Mi[6 + a] * t[2];
+        {   // dn = M' t = E M (E^-1 t); here E[] holds the E^-1 of the formula (S.Einv of the dynamics rows)
+            Lu3 lf;
+            lf.l10 = Mi[0]; lf.l20 = Mi[1]; lf.l21 = Mi[2]; lf.u01 = Mi[3]; lf.u02 = Mi[4]; lf.u12 = Mi[5]; lf.i0 = Mi[6]; lf.i1 = Mi[7]; lf.i2 = Mi[8];
+            double m0, m1, m2;
+            lu3_solve(lf, E[0] * t[0], E[1] * t[1], E[2] * t[2], m0, m1, m2);
+            dn[0] = m0 / E[0]; dn[1] = m1 / E[1]; dn[2] = m2 / E[2];
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a)
             dyv[a] = -(P1[6 * a] * dn[0] + P1[6 * a + 1] * dn[1] + P1[6 * a + 2] * dn[2] + P1[6 * a + 3] * u[0] +

@@ -92,7 +92,7 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
         return OBCA_E_INVAL;
     {   // fixed-time horizon: a multiple of N whose shift-in (N_fix - 5 columns of the previous plan) a free-time plan covers
         const int nf = d->N_fix > 0 ? d->N_fix : d->N;
-        if (nf < d->N || nf % d->N != 0 || nf > 127 || (nf > d->N && (nf - 5 > d->N || d->N > 31))) return OBCA_E_INVAL;
+        if (nf < d->N || nf % d->N != 0 || nf > 127 || (nf > d->N && nf - 5 > d->N)) return OBCA_E_INVAL;
     }
     for (int i = 0; i < d->n_static; ++i)
         if (d->m_static[i] < 1 || d->m_static[i] > OBCA_MAX_EDGES) return OBCA_E_INVAL;

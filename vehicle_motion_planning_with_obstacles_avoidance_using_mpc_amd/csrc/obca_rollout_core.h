@@ -200,14 +200,14 @@ RO_FN void prepare(const Dev& D, int b) {
         for (int j = 0; j < 3; ++j) xr[j * Nf1 + i] = xp[j * (D.Nm + 1) + i + 1];
     if (ratio > 1) {
         const double lastx = xr[Nf], lasty = xr[Nf1 + Nf];
-        // in place, back to front would overwrite sources: the sources are columns 0..N, the targets 0..N*ratio
-        double sx[32], sy[32];                    // N_free <= 31 when the ratio exceeds 1 (checked by obca_rollouts_create)
-        for (int i = 0; i <= N; ++i) { sx[i] = xr[i]; sy[i] = xr[Nf1 + i]; }
-        for (int i = 0; i < N; ++i) {
-            const double stx = (sx[i + 1] - sx[i]) / (double)ratio, sty = (sy[i + 1] - sy[i]) / (double)ratio;
+        // in place, last segment first: segment i reads columns i, i+1 and writes columns i*ratio .. (i+1)*ratio - 1, all
+        // beyond every column a LATER (smaller) segment still reads
+        for (int i = N - 1; i >= 0; --i) {
+            const double ax = xr[i], bx_ = xr[i + 1], ay = xr[Nf1 + i], by = xr[Nf1 + i + 1];
+            const double stx = (bx_ - ax) / (double)ratio, sty = (by - ay) / (double)ratio;
             for (int j = 0; j < ratio; ++j) {
-                xr[i * ratio + j] = (double)j * stx + sx[i];
-                xr[Nf1 + i * ratio + j] = (double)j * sty + sy[i];
+                xr[i * ratio + j] = (double)j * stx + ax;
+                xr[Nf1 + i * ratio + j] = (double)j * sty + ay;
             }
         }
         xr[Nf] = lastx; xr[Nf1 + Nf] = lasty;
