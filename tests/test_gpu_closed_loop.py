@@ -24,7 +24,8 @@ def test_demo8_closed_loop_reaches_fixed_time_phase():
     np.testing.assert_allclose(x_closed[1], [4.2, 4.0, 0.0], atol=1e-6)
     np.testing.assert_allclose(u_closed[0], [0.6, 0.0], atol=1e-6)
     xs = np.asarray(x_closed)
-    assert np.all(np.diff(xs[:, 0]) > 0)                        # keeps driving forward
+    # makes progress along the corridor (a fixed-time plan may legitimately wait or back up for a moving box: u in [-0.6, 0.6])
+    assert xs[-1, 0] > xs[0, 0] + 5.0 and np.all(np.diff(xs[:, 0]) > -0.6 * 2.5)
     assert np.all((xs[:, 1] > 1.75) & (xs[:, 1] < 8.25))        # stays clear of both walls
 
 
