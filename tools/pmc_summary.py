@@ -37,7 +37,8 @@ if kt:
         f.write("Kernel_Name,Grid_Size,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Duration_ms\n")
         for r in rows(kt):
             if "obca" in r["Kernel_Name"]:
-                f.write("%s,%s,%s,%s,%s,%s,%s,%s,%.4f\n" % (r["Kernel_Name"], r["Grid_Size"], r["Workgroup_Size"], r.get("LDS_Block_Size", ""),
+                f.write("%s,%s,%s,%s,%s,%s,%s,%s,%.4f\n" % (r["Kernel_Name"], r.get("Grid_Size", r.get("Grid_Size_X", "")),
+                        r.get("Workgroup_Size", r.get("Workgroup_Size_X", "")), r.get("LDS_Block_Size", ""),
                         r.get("Scratch_Size", ""), r.get("VGPR_Count", ""), r.get("Accum_VGPR_Count", ""), r.get("SGPR_Count", ""),
                         (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
 for name in ("bench_under_rocprof.json",):
