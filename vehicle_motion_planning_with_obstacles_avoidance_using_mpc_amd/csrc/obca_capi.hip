@@ -56,19 +56,18 @@ int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off)
     R_max = 3 + 3 * N + 3 + 2 * N1 + 2 * N + 2 * N + 2 + 2 * np + N1 * M + N1 * 4 * nO;
     int64_t t = 0;
     auto take = [&](int64_t c) { t += (c + 1) & ~int64_t(1); };
-    for (int i = 0; i < 4; ++i) take(n_max);                    // x, dx, gf, bx
-    for (int i = 0; i < 6; ++i) take(R_max);                    // y, Einv, yhat, gh, Lb, Ub
+    take(n_max); take(n_max > 120 ? n_max : 120); take(5 * N1 + 1); take(n_max);   // x, dx (also FG / Mall / mall), gf (compact), bx
+    for (int i = 0; i < 5; ++i) take(R_max);                    // y, Einv, gh, Lb, Ub
     take(3 * N1 + 3);                                           // dy of the soft rows
     take(N1); take(N1); take(2 * np); take(N1); take(N1); take(2 * np);
     take(2 * np); take(2 * np); take(2 * np);
     take(N1 * M * 2); take(N1 * M); take(3 * N1);
-    take(64 * N1); take(8 * N1);
+    take(36 * N1); take(8 * N1);                                // packed stage blocks, gradients
     {
         const int64_t nx = (n_max + 1) & ~1, nr = (R_max + 1) & ~1, ny = (int64_t)MW * 4 * np;
         take(ny > nx + nr ? ny : nx + nr);                      // Y, shared with xt and tmp
     }
     take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
-    take(48); take(64); take(8);                               // FG (one stage), Mall, mall
     take(32);                // lsv: iteration-level and line-search scalars
     take(8);                 // offm
     inst_off = (int)t;

@@ -115,7 +115,12 @@ struct Lay {
     __device__ __forceinline__ int il(int k) const { return k * NS + (k < N ? 5 : 3); }
     __device__ __forceinline__ int imu(int k) const { return il(k) + M; }
     __device__ __forceinline__ int iT() const { return n - 1; }
+    // compact storage of the objective gradient (it is zero on lambda, mu): stage k -> 5 entries (pose, input), then T
+    __device__ __forceinline__ int ig(int k) const { return 5 * k; }
+    __device__ __forceinline__ int igT() const { return 5 * (N + 1); }
 };
+// packed lower triangle of a symmetric 8 x 8 stage block
+__device__ __forceinline__ int LS(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 
 struct Inst {             // per-instance constants (registers, wave-uniform)
     double x0[3], u0[2], Ts, Tmax, term[3];
@@ -128,7 +133,7 @@ static_assert(sizeof(Inst) <= OBCA_INST_DOUBLES * sizeof(double), "Inst does not
 // LDS carve-up (all doubles)
 struct Sh {
     double *x, *xt, *dx, *gf, *bx;
-    double *y, *Einv, *yhat, *gh, *dy, *tmp; // row data other lanes read (dy: soft rows only); tmp: staging
+    double *y, *Einv, *gh, *dy, *tmp; // row data other lanes read (dy: soft rows only); tmp: staging
     double *Lb, *Ub;                         // row bounds (read-only after initialisation)
     double *ct, *st, *cc, *ctt, *stt, *cct;
     double *nu, *dnu, *crot;
@@ -269,7 +274,7 @@ __device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, cons
         for (int j = 0; j < 3; ++j) e[j] = pk[j] - S.xref[j * (L.N + 1) + k];
         for (int a = 0; a < 3; ++a) We[a] = W[3 * a] * e[0] + W[3 * a + 1] * e[1] + W[3 * a + 2] * e[2];
         part += e[0] * We[0] + e[1] * We[1] + e[2] * We[2];
-        if (GRAD) for (int a = 0; a < 3; ++a) S.gf[L.ip(k) + a] = sf * 2.0 * We[a];
+        if (GRAD) for (int a = 0; a < 3; ++a) S.gf[L.ig(k) + a] = sf * 2.0 * We[a];
         if (k < L.N) {
             const double* u = xv + L.iu(k);
             const double r0 = in.R1[0] * u[0] + in.R1[1] * u[1], r1 = in.R1[2] * u[0] + in.R1[3] * u[1];
@@ -291,7 +296,7 @@ __device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, cons
                 g0 += 2.0 * (in.R2[0] * q0 + in.R2[1] * q1) / (h * h);
                 g1 += 2.0 * (in.R2[2] * q0 + in.R2[3] * q1) / (h * h);
             }
-            if (GRAD) { S.gf[L.iu(k)] = sf * g0; S.gf[L.iu(k) + 1] = sf * g1; }
+            if (GRAD) { S.gf[L.ig(k) + 3] = sf * g0; S.gf[L.ig(k) + 4] = sf * g1; }
         }
     }
     double f = red_sum(part);
@@ -299,7 +304,7 @@ __device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, cons
         f += (L.N + 1) * (10.0 * T + T * T);
         if (GRAD) {
             gT = red_sum(gT) + (L.N + 1) * (10.0 + 2.0 * T);
-            if (lane == 0) S.gf[L.iT()] = sf * gT;
+            if (lane == 0) S.gf[L.igT()] = sf * gT;
         }
     }
     if (GRAD) SYNC();             // the lambda / mu entries of gf are zero for good (set once at the start)
@@ -308,7 +313,12 @@ __device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, cons
 
 // out = gf + J^T ymul (+ rotation rows with nu): gradient of the Lagrangian w.r.t. x.
 // One target entry per lane (gather form, deterministic).
-__device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const double* ym, double* out, int lane) {
+// HAT: multipliers yhat = y + ghat / E of the condensed rows (the soft rows keep y) evaluated on the fly -- storing
+// them cost one more row array in LDS
+template <bool HAT>
+__device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, double* out, int lane) {
+    auto YM = [&](int r) -> double { return HAT ? S.y[r] + S.gh[r] * S.Einv[r] : S.y[r]; };     // condensed rows
+    auto YS = [&](int r) -> double { return S.y[r]; };                                             // init, dyn (soft)
     const double* xv = S.x;
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
@@ -319,26 +329,26 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
         const double cs = S.ct[k], sn = S.st[k];
         double v;
         if (j < 3) {
-            v = S.gf[L.ip(k) + j];
-            if (k == 0) v += ym[L.r_init + j];
-            if (k >= 1) v += ym[L.r_dyn + 3 * (k - 1) + j];
+            v = S.gf[L.ig(k) + j];
+            if (k == 0) v += YS(L.r_init + j);
+            if (k >= 1) v += YS(L.r_dyn + 3 * (k - 1) + j);
             if (k < L.N) {
-                const double* yd = ym + L.r_dyn + 3 * k;
+                const double* yd = S.y + L.r_dyn + 3 * k;
                 v -= yd[j];
                 if (j == 2) {
                     const double vel = xv[L.iu(k)];
                     v -= h * vel * (-sn * yd[0] + cs * yd[1]);
                 }
             }
-            if (k == L.N && L.variant == 4) v += ym[L.r_term + j];
+            if (k == L.N && L.variant == 4) v += YM(L.r_term + j);
             if (j < 2) {
-                v += ym[L.r_xb + 2 * k + j];
-                if (k == L.N && L.variant == 6) v += ym[L.r_tx + j];
+                v += YM(L.r_xb + 2 * k + j);
+                if (k == L.N && L.variant == 6) v += YM(L.r_tx + j);
             }
             for (int i = 0; i < L.nO; ++i) {
                 const int pr = k * L.nO + i;
                 const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
-                const double yd = ym[L.r_dist + pr];
+                const double yd = YM(L.r_dist + pr);
                 if (j == 0) v += yd * c0;
                 else if (j == 1) v += yd * c1;
                 else {
@@ -349,12 +359,12 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
             out[L.ip(k) + j] = v;
         } else {
             const int c = j - 3;
-            v = S.gf[L.iu(k) + c];
-            const double* yd = ym + L.r_dyn + 3 * k;
+            v = S.gf[L.ig(k) + 3 + c];
+            const double* yd = S.y + L.r_dyn + 3 * k;
             v -= (c == 0) ? h * (cs * yd[0] + sn * yd[1]) : h * yd[2];
-            v += ym[L.r_ub + 2 * k + c];
-            v -= ym[L.r_acc + 2 * k + c] / h;
-            if (k + 1 < L.N) v += ym[L.r_acc + 2 * (k + 1) + c] / h;
+            v += YM(L.r_ub + 2 * k + c);
+            v -= YM(L.r_acc + 2 * k + c) / h;
+            if (k + 1 < L.N) v += YM(L.r_acc + 2 * (k + 1) + c) / h;
             out[L.iu(k) + c] = v;
         }
     }
@@ -369,9 +379,9 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
         const double* pk = xv + L.ip(k);
         const double tx = pk[0] + cs * in.off, ty = pk[1] + sn * in.off;
         double v = S.nu[2 * pr] * (cs * a0 + sn * a1) + S.nu[2 * pr + 1] * (-sn * a0 + cs * a1);
-        v += ym[L.r_norm + pr] * 2.0 * (a0 * c0 + a1 * c1);
-        v += ym[L.r_dist + pr] * (tx * a0 + ty * a1 - S.bobs[(size_t)k * L.M + j]);
-        v += ym[L.r_lam + t];
+        v += YM(L.r_norm + pr) * 2.0 * (a0 * c0 + a1 * c1);
+        v += YM(L.r_dist + pr) * (tx * a0 + ty * a1 - S.bobs[(size_t)k * L.M + j]);
+        v += YM(L.r_lam + t);
         out[L.il(k) + j] = v;
     }
     // mu
@@ -380,8 +390,8 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
         const int pr = k * L.nO + i;
         const double sgn = (j < 2) ? 1.0 : -1.0;
         double v = sgn * S.nu[2 * pr + (j & 1)];
-        v -= in.gego[j] * ym[L.r_dist + pr];
-        v += ym[L.r_mu + t];
+        v -= in.gego[j] * YM(L.r_dist + pr);
+        v += YM(L.r_mu + t);
         out[L.imu(k) + q] = v;
     }
     // time scale
@@ -389,15 +399,15 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, const dou
         double part = 0.0;
         for (int k = lane; k < L.N; k += NT) {
             const double* u = xv + L.iu(k);
-            const double* yd = ym + L.r_dyn + 3 * k;
+            const double* yd = S.y + L.r_dyn + 3 * k;
             part -= in.Ts * (u[0] * S.ct[k] * yd[0] + u[0] * S.st[k] * yd[1] + u[1] * yd[2]);
             for (int c = 0; c < 2; ++c) {
                 const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
-                part -= ym[L.r_acc + 2 * k + c] * (prev - u[c]) / (T * h);
+                part -= YM(L.r_acc + 2 * k + c) * (prev - u[c]) / (T * h);
             }
         }
         part = red_sum(part);
-        if (lane == 0) out[L.iT()] = S.gf[L.iT()] + part + (L.N + 1) * (ym[L.r_T] + ym[L.r_T + 1]);
+        if (lane == 0) out[L.iT()] = S.gf[L.igT()] + part + (L.N + 1) * (YM(L.r_T) + YM(L.r_T + 1));
     }
     SYNC();
 }
@@ -683,12 +693,13 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
         }
         Hpp[2][2] += hth;
         // write the 8x8 block over (dp(0:3), du_prev(3:5), dT(5), du(6:8)) and its gradient
-        double* H = S.Lall + 64 * k;
+        double* H = S.Lall + 36 * k;                    // packed lower triangle
         double* lv = S.lall + 8 * k;
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
+                if (b > a) continue;
                 double v = 0.0;
                 if (a < 3 && b < 3) v = Hpp[a][b];
                 else if (a >= 6 && b >= 6) v = Huu[a - 6][b - 6];
@@ -698,7 +709,7 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
                 else if ((a == 2 && b == 5) || (a == 5 && b == 2)) v = hpT;
                 else if (a == 5 && b >= 6) v = huT[b - 6];
                 else if (b == 5 && a >= 6) v = huT[a - 6];
-                H[8 * a + b] = v;
+                H[a * (a + 1) / 2 + b] = v;
             }
         lv[0] = S.bx[L.ip(k)]; lv[1] = S.bx[L.ip(k) + 1]; lv[2] = S.bx[L.ip(k) + 2];
         lv[3] = 0.0; lv[4] = 0.0; lv[5] = 0.0; lv[6] = lu0; lv[7] = lu1;
@@ -708,11 +719,11 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
         if (lane == 0) {
             const double w = (double)(L.N + 1);
             HTT += sf * 2.0 * w + dw * w + w * (S.Einv[L.r_T] + S.Einv[L.r_T + 1]);
-            S.Lall[8 * 5 + 5] += HTT;
+            S.Lall[LS(5, 5)] += HTT;
             S.lall[5] = S.bx[L.iT()];
         }
     } else if (lane == 0) {
-        S.Lall[8 * 5 + 5] = 1.0;                       // dT pinned to zero in the fixed-time variants
+        S.Lall[LS(5, 5)] = 1.0;                        // dT pinned to zero in the fixed-time variants
     }
     SYNC();
 }
@@ -865,12 +876,12 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
     SYNC();
     // fold the Schur complements into the stage blocks
     for (int k = lane; k <= L.N; k += NT) {
-        double* H = S.Lall + 64 * k;
+        double* H = S.Lall + 36 * k;
         double* lv = S.lall + 8 * k;
         for (int i = 0; i < L.nO; ++i) {
             const double* So = S.Sloc + (size_t)(k * L.nO + i) * 12;
             for (int a = 0; a < 3; ++a) {
-                for (int b = 0; b < 3; ++b) H[8 * a + b] -= 0.5 * (So[4 * a + b] + So[4 * b + a]);
+                for (int b = 0; b <= a; ++b) H[a * (a + 1) / 2 + b] -= 0.5 * (So[4 * a + b] + So[4 * b + a]);
                 lv[a] += So[4 * a + 3];
             }
         }
@@ -1036,7 +1047,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         double* qN = S.qk + 6 * L.N;
         if (lane < 36) {
             const int a = lane / 6, b = lane - 6 * a;
-            PN[lane] = (a < 3 && b < 3) ? S.Lall[64 * L.N + 8 * a + b] : 0.0;
+            PN[lane] = (a < 3 && b < 3) ? S.Lall[36 * L.N + LS(a, b)] : 0.0;
         } else if (lane < 42) {
             const int a = lane - 36;
             qN[a] = (a < 3) ? S.lall[8 * L.N + a] : 0.0;
@@ -1079,7 +1090,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
             for (int i = 0; i < 3; ++i)
                 yo[i] = dot3(P[6 * (3 + i) + 3], fb[3], P[6 * (3 + i) + 4], fb[4], P[6 * (3 + i) + 5], fb[5]) +
                         dot3(P[6 * (3 + i)], E[0] * s2[0], P[6 * (3 + i) + 1], E[1] * s2[1], P[6 * (3 + i) + 2], E[2] * s2[2]);
-            double v = S.Lall[64 * k + lane];
+            double v = S.Lall[36 * k + LS(a, b)];
 #pragma unroll
             for (int c = 0; c < 3; ++c) v = fma(fa[3 + c], yo[c], fma(fa[c], yp[c], v));
             S.Mall[lane] = v;
@@ -1348,12 +1359,12 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         double* p = smem;
         auto take = [&](int cnt) { double* q = p; p += (cnt + 1) & ~1; return q; };
         const int nmax = A.n_max, Rmax = A.R_max, np = L.npair, N1 = L.N + 1;
-        S.x = take(nmax); S.dx = take(nmax); S.gf = take(nmax); S.bx = take(nmax);
-        S.y = take(Rmax); S.Einv = take(Rmax); S.yhat = take(Rmax); S.gh = take(Rmax); S.Lb = take(Rmax); S.Ub = take(Rmax); S.dy = take(3 * N1 + 3);
+        S.x = take(nmax); S.dx = take(nmax > 120 ? nmax : 120); S.gf = take(5 * N1 + 1); S.bx = take(nmax);
+        S.y = take(Rmax); S.Einv = take(Rmax); S.gh = take(Rmax); S.Lb = take(Rmax); S.Ub = take(Rmax); S.dy = take(3 * N1 + 3);
         S.ct = take(N1); S.st = take(N1); S.cc = take(2 * np); S.ctt = take(N1); S.stt = take(N1); S.cct = take(2 * np);
         S.nu = take(2 * np); S.dnu = take(2 * np); S.crot = take(2 * np);
         S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
-        S.Lall = take(64 * N1); S.lall = take(8 * N1);
+        S.Lall = take(36 * N1); S.lall = take(8 * N1);
         {   // the trial point xt and the row staging array tmp are only alive while Y (local solutions, from the local
             // blocks to the recovery of the step) is dead, and vice versa: they share its storage
             const int nx = (nmax + 1) & ~1, nr = (Rmax + 1) & ~1, ny = MW * 4 * np;
@@ -1361,7 +1372,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             S.xt = S.Y; S.tmp = S.Y + nx;
         }
         S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
-        S.FG = take(48); S.Mall = take(64); S.mall = take(8);
+        // one stage's [F G], the 8 x 8 stage matrix and its gradient are only alive during the backward sweep, when the
+        // step dx (written by the forward pass after it) is not: they share its storage
+        S.FG = S.dx; S.Mall = S.dx + 48; S.mall = S.dx + 112;
         S.lsv = take(32);
         S.offm = reinterpret_cast<int*>(take(8));
         S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
@@ -1450,13 +1463,13 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     bool bad_bounds = false;
 
     // objective scaling: IPOPT's gradient rule applied to f + rho*sum(p+n)
-    for (int t = lane; t < L.n; t += NT) S.gf[t] = 0.0;        // the objective does not depend on lambda, mu
+    for (int t = lane; t <= L.igT(); t += NT) S.gf[t] = 0.0;  // (compact: the objective does not depend on lambda, mu)
     SYNC();
     eval_geom(L, S, S.x, S.ct, S.st, S.cc, lane);
     double f0 = eval_objective<true>(L, S, in, S.x, 1.0, lane);
     {
         double gm = 0.0;
-        for (int t = lane; t < L.n; t += NT) gm = dmaxabs(gm, S.gf[t]);
+        for (int t = lane; t <= L.igT(); t += NT) gm = dmaxabs(gm, S.gf[t]);
         gm = fmax(red_max(gm), O.rho);
         sf = (gm > OBCA_MAX_GRADIENT) ? OBCA_MAX_GRADIENT / gm : 1.0;
         rho = O.rho * sf;
@@ -1565,7 +1578,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         double th = 0.0, fobj = 0.0, delta_w = 0.0;
         if (!soc_pass) {
         // ---- gradient of the Lagrangian and optimality error ------------------------------------------
-        gather_grad(L, S, in, S.y, S.bx, lane);                    // bx doubles as scratch for grad_x L here
+        gather_grad<false>(L, S, in, S.bx, lane);                    // bx doubles as scratch for grad_x L here
         double rxmax = 0.0, crotmax = 0.0, nusum = 0.0, pnsum = 0.0;
         for (int t = lane; t < L.n; t += NT) rxmax = dmaxabs(rxmax, S.bx[t]);
         for (int t = lane; t < 2 * L.npair; t += NT) { crotmax = dmaxabs(crotmax, S.crot[t]); nusum += fabs(S.nu[t]); th += fabs(S.crot[t]); }
@@ -1633,11 +1646,10 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                     const double Ei = 1.0 / (q.iDs + q.iDp + q.iDn);
                     S.Einv[r] = Ei;
                     S.gh[r] = gh;
-                    S.yhat[r] = row_soft(L, r) ? y : (y + gh * Ei);
                 }
             }
             SYNC();
-            gather_grad(L, S, in, S.yhat, S.bx, lane);
+            gather_grad<true>(L, S, in, S.bx, lane);
             PROF(2)
             assemble_stages(L, S, in, sf, delta_w, lane);
             PROF(3)
@@ -1708,7 +1720,11 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 dphi += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
             }
         }
-        for (int t = lane; t < L.n; t += NT) dphi += S.gf[t] * S.dx[t];
+        for (int t = lane; t < L.n; t += NT) {                       // same lane <-> entry assignment as a dense gradient
+            const int k = t / L.NS, q = t - k * L.NS;
+            if (L.free_T && t == L.iT()) dphi += S.gf[L.igT()] * S.dx[t];
+            else if (q < (k < L.N ? 5 : 3)) dphi += S.gf[L.ig(k) + q] * S.dx[t];
+        }
         a_max = red_min(a_max); a_z = red_min(a_z); dphi = red_sum(dphi); phi = red_sum(phi) + GET(IV_F);
         double alpha_min;
         // the two powers of the switching condition do not depend on the step length: once per iteration, not per trial
