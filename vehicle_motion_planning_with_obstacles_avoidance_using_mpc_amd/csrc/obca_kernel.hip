@@ -463,7 +463,7 @@ __device__ double row_jdx(const Lay& L, const Sh& S, const Inst& in, int r) {
 // need goes to LDS: y (gather / curvature), yhat, Einv, ghat (assembly, Riccati).
 template <int RPL>
 struct Rows {
-    double s[RPL], p[RPL], n[RPL], y[RPL], zL[RPL], zU[RPL], zp[RPL], zn[RPL], g[RPL], dy[RPL];
+    double s[RPL], p[RPL], n[RPL], zL[RPL], zU[RPL], zp[RPL], zn[RPL], g[RPL], dy[RPL];
     double iDs[RPL], iDp[RPL], iDn[RPL], rs[RPL], rp[RPL], rn[RPL];
 };
 
@@ -481,7 +481,7 @@ __device__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double 
             const bool eq = row_iseq(L, r);
             const double lo_ = S.Lb[r], up_ = S.Ub[r];
             const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
-            const double s = W.s[j], y = W.y[j], p = W.p[j], n = W.n[j];
+            const double s = W.s[j], y = S.y[r], p = W.p[j], n = W.n[j];
             const double zL = hasL ? W.zL[j] : 0.0, zU = hasU ? W.zU[j] : 0.0, zp = W.zp[j], zn = W.zn[j];
             if (!eq) dual = dmaxabs(dual, -y - zL + zU);
             dual = dmaxabs(dual, rho - y - zp);
@@ -529,7 +529,7 @@ __device__ ErrFirst ipm_errors_first(const Lay& L, const Sh& S, const Rows<RPL>&
             const bool eq = row_iseq(L, r);
             const double lo_ = S.Lb[r], up_ = S.Ub[r];
             const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
-            const double s = W.s[j], y = W.y[j], p = W.p[j], n = W.n[j];
+            const double s = W.s[j], y = S.y[r], p = W.p[j], n = W.n[j];
             const double zL = hasL ? W.zL[j] : 0.0, zU = hasU ? W.zU[j] : 0.0, zp = W.zp[j], zn = W.zn[j];
             if (!eq) dual = dmaxabs(dual, -y - zL + zU);
             dual = dmaxabs(dual, rho - y - zp);
@@ -1493,7 +1493,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
             const int r = lane + NT * j;
-            W.s[j] = 0.0; W.p[j] = 1.0; W.n[j] = 1.0; W.y[j] = 0.0;
+            W.s[j] = 0.0; W.p[j] = 1.0; W.n[j] = 1.0;
             W.zL[j] = 0.0; W.zU[j] = 0.0; W.zp[j] = 1.0; W.zn[j] = 1.0; W.g[j] = 0.0; W.dy[j] = 0.0;
             W.iDs[j] = 0.0; W.iDp[j] = 1.0; W.iDn[j] = 1.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
             if (r < L.R) {
@@ -1515,10 +1515,10 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const double en = a + sqrt(a * a + mu * rr / (2.0 * rho));
                 const double ep = rr + en;
                 W.g[j] = g; W.s[j] = s; W.p[j] = ep; W.n[j] = en;
-                W.zp[j] = mu / ep; W.zn[j] = mu / en; W.y[j] = rho - mu / ep;
+                W.zp[j] = mu / ep; W.zn[j] = mu / en;
                 W.zL[j] = (!eq && hasL) ? 1.0 : 0.0;
                 W.zU[j] = (!eq && hasU) ? 1.0 : 0.0;
-                S.y[r] = W.y[j];
+                S.y[r] = rho - mu / ep;
             }
         }
         bad_bounds = red_or(bb) != 0;
@@ -1637,7 +1637,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const int r = lane + NT * j;
                 if (r < L.R) {
                     const bool eq = row_iseq(L, r);
-                    const double y = W.y[j];
+                    const double y = S.y[r];
                     const double lo_ = S.Lb[r], up_ = S.Ub[r];
                     const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], y, W.zL[j], W.zU[j], W.zp[j],
                                           W.zn[j], mu, rho, delta_w);
@@ -1688,7 +1688,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const double dy = S.tmp[r];
                 W.dy[j] = dy;
                 {   // cached for the line search and the update (not kept live across the factorisation)
-                    const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], W.y[j], W.zL[j], W.zU[j], W.zp[j],
+                    const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], S.y[r], W.zL[j], W.zU[j], W.zp[j],
                                           W.zn[j], mu, rho, delta_w);
                     W.iDs[j] = q.iDs; W.iDp[j] = q.iDp; W.iDn[j] = q.iDn; W.rs[j] = q.rs; W.rp[j] = q.rp; W.rn[j] = q.rn;
                 }
@@ -1697,7 +1697,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const double dp = (dy - W.rp[j]) * W.iDp[j];
                 const double dn = (-dy - W.rn[j]) * W.iDn[j];
                 const double s = W.s[j], p = W.p[j], n = W.n[j];
-                double gs = eq ? 0.0 : W.rs[j] + W.y[j];
+                double gs = eq ? 0.0 : W.rs[j] + S.y[r];
                 if (hasL) {
                     const double sl = s - lo_, zL = W.zL[j];
                     if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
@@ -1911,8 +1911,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 W.zp[j] = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
                 W.zn[j] = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
                 W.s[j] = s; W.p[j] = p; W.n[j] = n;
-                W.y[j] += a_try * dy;
-                S.y[r] = W.y[j];
+                S.y[r] += a_try * dy;
             }
         }
         for (int t = lane; t < 2 * L.npair; t += NT) { S.nu[t] += a_try * S.dnu[t]; S.crot[t] = S.bx[t]; }
