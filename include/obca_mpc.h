@@ -149,7 +149,9 @@ int obca_set_certificate_buffers(obca_handle* h, double* z, double* y);
  * working set still fits the LDS (<= 768 rows, e.g. N = 20 with three obstacles); else the lane-per-instance kernel.
  * 1 = one wavefront per instance; 2 = lane-per-instance (64 instances per wavefront, working set in an HBM workspace
  * owned by the handle; any shape, e.g. N = 20 with five obstacles); 3 = four wavefronts per instance.
- * Returns OBCA_E_LDS if mode 1 / 3 cannot hold the shape. */
+ * 4 = two wavefronts per instance with a 256-register budget, i.e. two waves per SIMD (experimental; shapes with <= 384 rows
+ * and <= 64 KB of LDS; bit-identical to mode 1, measured 5 % slower on the headline workload -- DESIGN.md section 4a).
+ * Returns OBCA_E_LDS if mode 1 / 3 / 4 cannot hold the shape. */
 int obca_set_mode(obca_handle* h, int mode);
 
 /* Diagnostic: device buffer [max_batch,20] receiving per-phase shader-clock totals of each instance.

@@ -14,6 +14,8 @@ extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2);
 extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2);
 extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2);          // four wavefronts per instance (obca_kernel_mw.hip)
 extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2);
+extern "C" __global__ void obca_ipm_kernel_w2_r2(ObcaLaunch A, ObcaLaunch A2);          // two wavefronts per instance (obca_kernel_w2.hip)
+extern "C" __global__ void obca_ipm_kernel_w2_r3(ObcaLaunch A, ObcaLaunch A2);
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
 struct obca_handle {
@@ -123,7 +125,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     h->mode = 0;
     if (const char* e = getenv("OBCA_MODE")) {
         const int m = atoi(e);                                     // out of range or not available for this shape: auto
-        if (m >= 0 && m <= 3 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok)) h->mode = m;
+        if (m >= 0 && m <= 4 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok) && !(m == 4 && !(h->wave_ok && h->R_max <= 384))) h->mode = m;
     }
     h->ws = nullptr; h->d_offm = nullptr;
     h->ws_stride = ((size_t)d->max_batch + 63) / 64 * 64;
@@ -150,7 +152,8 @@ extern "C" void obca_destroy(obca_handle* h) {
 }
 
 extern "C" int obca_set_mode(obca_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 3) return OBCA_E_INVAL;
+    if (!h || mode < 0 || mode > 4) return OBCA_E_INVAL;
+    if (mode == 4 && !(h->wave_ok && h->R_max <= 384 && h->lds_bytes + 64 <= 64 * 1024)) return OBCA_E_LDS;
     if (mode == 1 && !h->wave_ok) return OBCA_E_LDS;
     if (mode == 3 && !h->mw_ok) return OBCA_E_LDS;
     h->mode = mode;
@@ -257,6 +260,15 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     if (h->mode == 3 && !h->mw_ok) return OBCA_E_LDS;
     // one wavefront per instance where the rows fit its registers; four wavefronts (one CU) per instance for bigger
     // shapes that still fit the LDS; the lane kernel for everything else
+    if (h->mode == 4) {                              // two wavefronts per instance (experimental)
+        ObcaLaunch L2 = L;
+        L2.prm.opt.rho *= OBCA_RHO_ESCALATION;
+        if (h->R_max <= 256)
+            hipLaunchKernelGGL(obca_ipm_kernel_w2_r2, dim3(B), dim3(128), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
+        else
+            hipLaunchKernelGGL(obca_ipm_kernel_w2_r3, dim3(B), dim3(128), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
+        return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
+    }
     const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw || !lane) {

@@ -728,6 +728,162 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
     SYNC();
 }
 
+// ---------------------------------------------------------------- level 1, cooperative form (two-wavefront kernel)
+// FOUR lanes (one DPP quad) per (stage, obstacle) pair.  Lane q of the quad owns rows q, q+4, q+8 of the 10x10 block (22
+// doubles instead of the 55 of the whole lower triangle) and right-hand side column q of [G_x G_y G_theta rloc]; column j
+// of the elimination and the factor entries of the back substitution travel by quad broadcasts.  Every entry goes through
+// the same operations in the same order as in local_blocks below, so the two forms give bit-identical Y and Schur
+// complements -- at ~60 instead of ~135 doubles of registers, which is what lets two waves share a SIMD.
+#if OBCA_NT == 128
+template <int SRC>
+__device__ __forceinline__ double qbc(double v) { return dpp_move<SRC | (SRC << 2) | (SRC << 4) | (SRC << 6)>(v); }
+#define QBC(src, v) ((src) == 0 ? qbc<0>(v) : (src) == 1 ? qbc<1>(v) : (src) == 2 ? qbc<2>(v) : qbc<3>(v))
+
+__device__ int local_blocks_quad(const Lay& L, const Sh& S, const Inst& in, double dw, int lane) {
+    int bad = 0;
+    for (int w = lane; w < 4 * L.npair; w += NT) {
+        const int pr = w >> 2, q = w & 3;
+        const int k = pr / L.nO, i = pr - k * L.nO;
+        const int o0 = S.offm[i], m = S.offm[i + 1] - o0;
+        const double cs = S.ct[k], sn = S.st[k];
+        const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
+        const double* pk = S.x + L.ip(k);
+        const double tx = pk[0] + cs * in.off, ty = pk[1] + sn * in.off;
+        const double yn = S.y[L.r_norm + pr], En = S.Einv[L.r_norm + pr];
+        const double yd = S.y[L.r_dist + pr], Ed = S.Einv[L.r_dist + pr];
+        const double nu1 = S.nu[2 * pr], nu2 = S.nu[2 * pr + 1];
+        const double dth = -sn * c0 + cs * c1;
+        double a0[OBCA_MAX_EDGES], a1[OBCA_MAX_EDGES], gn[OBCA_MAX_EDGES], gd[NW];
+#pragma unroll
+        for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
+            const bool on = j < m;
+            a0[j] = on ? S.Aobs[((size_t)k * L.M + o0 + j) * 2] : 0.0;
+            a1[j] = on ? S.Aobs[((size_t)k * L.M + o0 + j) * 2 + 1] : 0.0;
+            const double bj = on ? S.bobs[(size_t)k * L.M + o0 + j] : 0.0;
+            gn[j] = 2.0 * (a0[j] * c0 + a1[j] * c1);
+            gd[j] = on ? (tx * a0[j] + ty * a1[j] - bj) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gd[OBCA_MAX_EDGES + j] = -in.gego[j];
+        // my rows: slot 0 = lambda row q, slot 1 = mu row 4 + q, slot 2 = rotation row 8 + q (q < 2)
+        double R[3][MW];
+        {
+            const bool on = q < m;                              // lambda slot q in use
+            const double a0a = on ? S.Aobs[((size_t)k * L.M + o0 + q) * 2] : 0.0;
+            const double a1a = on ? S.Aobs[((size_t)k * L.M + o0 + q) * 2 + 1] : 0.0;
+            const double bja = on ? S.bobs[(size_t)k * L.M + o0 + q] : 0.0;
+            const double gna = 2.0 * (a0a * c0 + a1a * c1);
+            const double gda = on ? (tx * a0a + ty * a1a - bja) : 0.0;
+            const double dia = on ? (dw + S.Einv[L.r_lam + k * L.M + o0 + (on ? q : 0)]) : 1.0;
+#pragma unroll
+            for (int b = 0; b < OBCA_MAX_EDGES; ++b) {
+                double v = Ed * gda * gd[b];
+                v += En * gna * gn[b] + yn * 2.0 * (a0a * a0[b] + a1a * a1[b]);
+                R[0][b] = v;
+            }
+            // diagonal of my lambda row: KP(j, j) += on ? dw + Einv : 1
+#pragma unroll
+            for (int b = 0; b < OBCA_MAX_EDGES; ++b) R[0][b] = (b == q) ? R[0][b] + dia : R[0][b];
+            const double gdm = -in.gego[q];                     // gd[4 + q]
+#pragma unroll
+            for (int b = 0; b < NW; ++b) R[1][b] = Ed * gdm * gd[b];
+            const double dim = dw + S.Einv[L.r_mu + k * 4 * L.nO + 4 * i + q];
+#pragma unroll
+            for (int b = OBCA_MAX_EDGES; b < NW; ++b) R[1][b] = (b == OBCA_MAX_EDGES + q) ? R[1][b] + dim : R[1][b];
+            // rotation rows (lanes 0 and 1)
+#pragma unroll
+            for (int b = 0; b < OBCA_MAX_EDGES; ++b) R[2][b] = (q == 0) ? cs * a0[b] + sn * a1[b] : -sn * a0[b] + cs * a1[b];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                R[2][OBCA_MAX_EDGES + j] = (q == 0) ? ((j == 0) ? 1.0 : (j == 2) ? -1.0 : 0.0) : ((j == 1) ? 1.0 : (j == 3) ? -1.0 : 0.0);
+            R[2][NW] = 0.0; R[2][NW + 1] = 0.0;
+        }
+        // my right-hand side column (q = 0, 1, 2: G_x, G_y, G_theta; q = 3: rloc)
+        double Gq[MW], Yv[MW];
+#pragma unroll
+        for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
+            const bool on = j < m;
+            const double g0 = Ed * gd[j] * c0 + yd * a0[j];
+            const double g1 = Ed * gd[j] * c1 + yd * a1[j];
+            const double g2 = Ed * gd[j] * in.off * dth + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
+                              nu1 * (-sn * a0[j] + cs * a1[j]) + nu2 * (-cs * a0[j] - sn * a1[j]);
+            const double g3 = on ? -S.bx[L.il(k) + o0 + (on ? j : 0)] : 0.0;
+            Gq[j] = q == 0 ? g0 : q == 1 ? g1 : q == 2 ? g2 : g3;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = OBCA_MAX_EDGES + j;
+            const double g0 = Ed * gd[a] * c0, g1 = Ed * gd[a] * c1, g2 = Ed * gd[a] * in.off * dth;
+            const double g3 = -S.bx[L.imu(k) + 4 * i + j];
+            Gq[a] = q == 0 ? g0 : q == 1 ? g1 : q == 2 ? g2 : g3;
+        }
+        Gq[NW] = q == 2 ? dth : q == 3 ? -S.crot[2 * pr] : 0.0;
+        Gq[NW + 1] = q == 2 ? -cs * c0 - sn * c1 : q == 3 ? -S.crot[2 * pr + 1] : 0.0;
+        // the original column waits in its slot of Y (LDS) until the Schur complement needs it again
+        double* Yo = S.Y + (size_t)pr * (MW * 4) + q;
+#pragma unroll
+        for (int a = 0; a < MW; ++a) { Yv[a] = Gq[a]; Yo[4 * a] = Gq[a]; }
+        // LDL^T without pivoting, forward substitution fused; column j comes by quad broadcast from the rows' owners.  The
+        // reciprocal pivot replaces the pivot in its owner's row (the back substitution fetches it from there).
+        int nneg = 0;
+#pragma unroll
+        for (int j = 0; j < MW; ++j) {
+            const double d = QBC(j & 3, R[j >> 2][j]);
+            const double dinv = 1.0 / d;
+            nneg += dinv < 0.0 ? 1 : 0;
+            if (!(fabs(dinv) < INFINITY)) bad = 1;              // zero or NaN pivot
+            double cb[MW];                                       // K[b][j], b > j, unscaled
+#pragma unroll
+            for (int b = 0; b < MW; ++b)
+                if (b > j) cb[b] = QBC(b & 3, R[b >> 2][j]);
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                // my row a = 4 sl + q: rows above j are updated
+                const int abase = 4 * sl;
+                const double la = R[sl][j] * dinv;
+#pragma unroll
+                for (int b = 0; b < MW; ++b) {
+                    if (b > j && b <= abase + 3) {
+                        const bool act = (abase + q > j) && (b <= abase + q);
+                        const double upd = R[sl][b] - la * cb[b];
+                        R[sl][b] = act ? upd : R[sl][b];
+                    }
+                }
+                if (abase + 3 >= j && abase <= j) R[sl][j] = (abase + q > j) ? la : (abase + q == j) ? dinv : R[sl][j];
+                else if (abase > j) R[sl][j] = la;                // KP(a, j) *= dinv[j]
+            }
+#pragma unroll
+            for (int a = 0; a < MW; ++a)
+                if (a > j) Yv[a] -= (cb[a] * dinv) * Yv[j];
+        }
+        if (nneg != 2) bad = 1;
+#pragma unroll
+        for (int jj = 0; jj < MW; ++jj) {
+            const int j = MW - 1 - jj;
+            double v = Yv[j] * QBC(j & 3, R[j >> 2][j]);
+#pragma unroll
+            for (int a = 0; a < MW; ++a)
+                if (a > j) v -= QBC(a & 3, R[a >> 2][j]) * Yv[a];
+            Yv[j] = v;
+        }
+        // my column of the Schur complement G'Y (G_x, G_y, G_theta from lanes 0, 1, 2), then of Y = Kloc^-1 [G | rloc]
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < MW; ++e) {
+            const double ge = Yo[4 * e];
+            s0 += qbc<0>(ge) * Yv[e];
+            s1 += qbc<1>(ge) * Yv[e];
+            s2 += qbc<2>(ge) * Yv[e];
+        }
+#pragma unroll
+        for (int a = 0; a < MW; ++a) Yo[4 * a] = Yv[a];
+        double* So = S.Sloc + (size_t)pr * 12 + q;
+        So[0] = s0; So[4] = s1; So[8] = s2;
+    }
+    return bad;
+}
+#endif
+
 // ---------------------------------------------------------------- level 1: local blocks, one lane per pair
 // Writes Y[pr] = Kloc^-1 [G | rloc] (MW x 4) and Sloc[pr] = (G^T Y_G (3x3), G^T Y_r (3)). Returns 1 on a
 // wrong-sign pivot.
@@ -736,9 +892,14 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
 #ifdef NO_LOCAL
     return 0;
 #endif
+#if OBCA_NT == 128
+    bad = local_blocks_quad(L, S, in, dw, lane);
+    for (int w = 0; w < 0; ++w) {
+#else
     // TWO lanes per pair: both factor the block (registers), each solves two of the four right-hand sides
     // [G_x G_y | G_theta rloc] and produces the matching columns of Y and of the Schur complement G'Y.
     for (int w = lane; w < 2 * L.npair; w += NT) {
+#endif
         const int pr = w >> 1;
         const bool hi = (w & 1) != 0;
         const int k = pr / L.nO, i = pr - k * L.nO;
@@ -1068,28 +1229,36 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
             // the others would only repeat it and compete for the LDS)
             const double* Pl = S.Pk + 36 * (k + 1);
             const double* ql = S.qk + 6 * (k + 1);
-            double P[36];
+            // P is used in two halves (rows 0-2: LU and the two right-hand sides; rows 3-5: the second block of P~ f), loaded
+            // one after the other -- all 36 entries at once were the register peak of the sweep
+            double Pa[18], Pb[18];
 #pragma unroll
-            for (int i = 0; i < 36; ++i) P[i] = Pl[i];
+            for (int i = 0; i < 18; ++i) Pa[i] = Pl[i];
             Lu3 lu;
-            bad |= lu3_factor(P, 6, E, lu);
+            bad |= lu3_factor(Pa, 6, E, lu);
             const int a = lane >> 3, b = lane & 7;
-            double fa[6], fb[6];
+            double fb[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) { fa[c] = S.FG[8 * c + a]; fb[c] = S.FG[8 * c + b]; }
+            for (int c = 0; c < 6; ++c) fb[c] = S.FG[8 * c + b];
             double w3[3], t3[3], u3[3], yp[3], s2[3], yo[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                w3[i] = dot3(P[6 * i + 3], fb[3], P[6 * i + 4], fb[4], P[6 * i + 5], fb[5]);          // Ppo f_o
-                t3[i] = dot3(P[6 * i], fb[0], P[6 * i + 1], fb[1], P[6 * i + 2], fb[2]) + w3[i];
+                w3[i] = dot3(Pa[6 * i + 3], fb[3], Pa[6 * i + 4], fb[4], Pa[6 * i + 5], fb[5]);          // Ppo f_o
+                t3[i] = dot3(Pa[6 * i], fb[0], Pa[6 * i + 1], fb[1], Pa[6 * i + 2], fb[2]) + w3[i];
                 u3[i] = fma(Dv[i], fb[i], -w3[i]);
             }
             lu3_solve(lu, t3[0], t3[1], t3[2], yp[0], yp[1], yp[2]);
             lu3_solve(lu, u3[0], u3[1], u3[2], s2[0], s2[1], s2[2]);
+            __asm__ volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 18; ++i) Pb[i] = Pl[18 + i];
+            double fa[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) fa[c] = S.FG[8 * c + a];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                yo[i] = dot3(P[6 * (3 + i) + 3], fb[3], P[6 * (3 + i) + 4], fb[4], P[6 * (3 + i) + 5], fb[5]) +
-                        dot3(P[6 * (3 + i)], E[0] * s2[0], P[6 * (3 + i) + 1], E[1] * s2[1], P[6 * (3 + i) + 2], E[2] * s2[2]);
+                yo[i] = dot3(Pb[6 * i + 3], fb[3], Pb[6 * i + 4], fb[4], Pb[6 * i + 5], fb[5]) +
+                        dot3(Pb[6 * i], E[0] * s2[0], Pb[6 * i + 1], E[1] * s2[1], Pb[6 * i + 2], E[2] * s2[2]);
             double v = S.Lall[36 * k + LS(a, b)];
 #pragma unroll
             for (int c = 0; c < 3; ++c) v = fma(fa[3 + c], yo[c], fma(fa[c], yp[c], v));
@@ -1101,7 +1270,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
                 for (int i = 0; i < 6; ++i) q[i] = ql[i];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    r1[i] = q[i] - dot3(P[6 * i], gh[0], P[6 * i + 1], gh[1], P[6 * i + 2], gh[2]);
+                    r1[i] = q[i] - dot3(Pl[6 * i], gh[0], Pl[6 * i + 1], gh[1], Pl[6 * i + 2], gh[2]);
                     r2[i] = fma(Dv[i], gh[i], q[i]);
                 }
                 lu3_solve(lu, r1[0], r1[1], r1[2], z1[0], z1[1], z1[2]);
@@ -1109,7 +1278,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
                 double w = S.lall[8 * k + a];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const double zo = q[3 + i] - dot3(P[6 * (3 + i)], E[0] * z2[0], P[6 * (3 + i) + 1], E[1] * z2[1], P[6 * (3 + i) + 2], E[2] * z2[2]);
+                    const double zo = q[3 + i] - dot3(Pb[6 * i], E[0] * z2[0], Pb[6 * i + 1], E[1] * z2[1], Pb[6 * i + 2], E[2] * z2[2]);
                     w = fma(fa[3 + i], zo, fma(fa[i], z1[i], w));
                 }
                 S.mall[a] = w;
@@ -2078,6 +2247,10 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches,
     rollout_fused_body<6>(*Dp, launches, n_steps);
 }
 
+#elif OBCA_NT == 128
+// two wavefronts per instance, two workgroups' worth of waves per SIMD (register budget capped at 256): rows r = thread + 128 j
+extern "C" __global__ void __launch_bounds__(OBCA_NT, 2) obca_ipm_kernel_w2_r2(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<2>(A, A2); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT, 2) obca_ipm_kernel_w2_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
 #else
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
 extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
