@@ -9,14 +9,16 @@ from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver impor
 
 what = sys.argv[1] if len(sys.argv) > 1 else "c2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-if what == "c2":
+mode = None
+if what in ("c2", "c2w2"):
     B, N = 8192, 5
     b = sc.make_batch(B, N)
+    mode = "twowave" if what == "c2w2" else None
 elif what == "c3g":
     B, N = 2048, 20
     b = sc.make_batch_c3(B, N, gated=True, procs=16)
-if what in ("c2", "c3g"):
-    s = BatchSolver(N, b["m"], max_batch=B)
+if what in ("c2", "c2w2", "c3g"):
+    s = BatchSolver(N, b["m"], max_batch=B, mode=mode)
     dv = {k: torch.as_tensor(b[k], device="cuda") for k in ("variant", "x0", "u0", "xref", "A", "b", "Ts", "term")}
     out = None
     for _ in range(reps):
