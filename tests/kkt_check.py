@@ -105,6 +105,23 @@ def _polygon_vertices(A, b):
     return np.array(V)
 
 
+def _wedge_vertices(A, b, reach=1e4):
+    """two half-planes (an obstacle given by three vertices = two edges, e.g. demo9's walls): the unbounded wedge cut off
+    far outside the map -- apex, a far point on each boundary ray, and their sum"""
+    a1, a2 = A[0], A[1]
+    det = a1[0] * a2[1] - a1[1] * a2[0]
+    if abs(det) < 1e-12:
+        return None
+    apex = np.array([(b[0] * a2[1] - a1[1] * b[1]) / det, (a1[0] * b[1] - b[0] * a2[0]) / det])
+    d1 = np.array([-a1[1], a1[0]]) / np.linalg.norm(a1)          # along line 1, into {a2 q <= b2}
+    if a2 @ d1 > 0:
+        d1 = -d1
+    d2 = np.array([-a2[1], a2[0]]) / np.linalg.norm(a2)          # along line 2, into {a1 q <= b1}
+    if a1 @ d2 > 0:
+        d2 = -d2
+    return np.array([apex, apex + reach * d1, apex + reach * (d1 + d2), apex + reach * d2])
+
+
 def polytope_distance(car, A, b):
     """Euclidean distance between the convex polygon `car` (vertices) and the obstacle {q: A q <= b}; negative values
     measure penetration along the best separating row (only their sign matters to the tests)."""
@@ -114,7 +131,7 @@ def polytope_distance(car, A, b):
     gaps = (np.min(car @ A.T, axis=0) - b) / nrm            # every row is a separating-axis candidate (lower bounds)
     if len(b) == 1:
         return float(gaps[0])                               # half-plane: exact
-    V = _polygon_vertices(A, b) if len(b) >= 3 else None
+    V = _polygon_vertices(A, b) if len(b) >= 3 else _wedge_vertices(A, b)
     if V is None:                                           # wedge / degenerate: small QP  min |p - q|^2
         from scipy.optimize import minimize
         cons = [dict(type="ineq", fun=lambda v: b - A @ v[2:4])]

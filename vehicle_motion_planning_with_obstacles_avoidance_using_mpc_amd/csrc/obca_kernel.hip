@@ -1249,7 +1249,9 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
             }
             lu3_solve(lu, t3[0], t3[1], t3[2], yp[0], yp[1], yp[2]);
             lu3_solve(lu, u3[0], u3[1], u3[2], s2[0], s2[1], s2[2]);
-            __asm__ volatile("" ::: "memory");
+#if OBCA_NT == 128
+            __asm__ volatile("" ::: "memory");     // (256-register build only: keeps the second half's loads behind the first half's uses)
+#endif
 #pragma unroll
             for (int i = 0; i < 18; ++i) Pb[i] = Pl[18 + i];
             double fa[6];
