@@ -1272,7 +1272,11 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
                 for (int i = 0; i < 6; ++i) q[i] = ql[i];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
+#if OBCA_NT == 128          // (256-register build: rows 0-2 are read again from LDS instead of being kept in registers)
                     r1[i] = q[i] - dot3(Pl[6 * i], gh[0], Pl[6 * i + 1], gh[1], Pl[6 * i + 2], gh[2]);
+#else
+                    r1[i] = q[i] - dot3(Pa[6 * i], gh[0], Pa[6 * i + 1], gh[1], Pa[6 * i + 2], gh[2]);
+#endif
                     r2[i] = fma(Dv[i], gh[i], q[i]);
                 }
                 lu3_solve(lu, r1[0], r1[1], r1[2], z1[0], z1[1], z1[2]);
