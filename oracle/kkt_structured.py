@@ -76,12 +76,18 @@ def soft_min(P, q, E):
     return Pt, qt, Mi, piv
 
 
-def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_init, free_T):
+def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_init, free_T, split=0):
     """
     H, b     dense condensed Hessian / gradient in x-space (blocks are read out of it)
     Jrot     dense Jacobian of the hard rotation rows (rows ordered k-major, i, 2), crot residuals
     A,B,tcol per-stage dynamics linearisation: row function J dx = dp_{k+1} - A dp_k - B du_k - tcol dT
     returns dx, dnu (rot multipliers step), dy_init(3), dy_dyn(N,3), pivots-ok flag
+
+    split = m > 0: TWO-SIDED sweep (blueprint of the parallel Riccati): the backward recursion runs from stage N down to m
+    and gives the cost-to-go V_m(xi_m); a forward recursion runs from stage 0 up to m and gives the cost-to-arrive W_m(xi_m)
+    (stages 0..m-1 eliminated: per stage the 5 variables (dp_k, du_{k-1}) -- 3 at stage 0, where du_{-1} = 0 -- by LDL^T, the
+    Schur complement lands on (dp_{k+1}, du_k, dT)); the two meet in one 6x6 solve for xi_m, and the two halves are
+    recovered outwards independently.  Same inertia test by additivity: every eliminated block positive definite.
     """
     N, n = p.N, p.n
     nO = p.nObs
@@ -126,10 +132,10 @@ def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_i
     if not free_T:
         pass
     gains = [None] * N
-    for k in range(N - 1, -1, -1):
-        Pt, qt, Mi, piv = soft_min(P, q, E_dyn[k])
-        if np.any(piv <= 0):
-            ok = False
+    m_split = int(split)
+    assert 0 <= m_split < N or N == 0
+
+    def stage_blocks(k):
         ipk, iuk = p.ip(k), p.iu(k)
         F = np.zeros((6, 6))
         F[:3, :3] = A[k]
@@ -159,6 +165,13 @@ def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_i
             Lxx[5, 5] = 1.0
         Luu = blk(iuk, 2, iuk, 2)
         lu = b[iuk:iuk + 2]
+        return F, G, f, Lxx, Lxu, Luu, lx, lu
+
+    for k in range(N - 1, m_split - 1, -1):
+        Pt, qt, Mi, piv = soft_min(P, q, E_dyn[k])
+        if np.any(piv <= 0):
+            ok = False
+        F, G, f, Lxx, Lxu, Luu, lx, lu = stage_blocks(k)
         Pf = Pt @ f + qt
         Mxx = Lxx + F.T @ Pt @ F
         Mxu = Lxu + F.T @ Pt @ G
@@ -174,26 +187,111 @@ def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_i
         qn = mx + Mxu @ kap
         gains[k] = (Kg, kap, Mi, P.copy(), q.copy(), F, G, f)
         P, q = 0.5 * (Pn + Pn.T), qn
-    # stage 0: u_prev step is zero (u_{-1} = u0 is data); soft initial condition; then dT
-    Pt, qt, Mi0, piv = soft_min(P, q, E_init)
-    if np.any(piv <= 0):
-        ok = False
-    phat0 = -gh_init
-    dT = 0.0
-    if free_T:
-        if Pt[5, 5] <= 0:
-            ok = False
-        dT = -(qt[5] + Pt[5, :3] @ phat0) / Pt[5, 5]
-    o = np.array([0.0, 0.0, dT])
-    dp = Mi0.T @ (phat0 - E_init * (P[:3, 3:] @ o) - E_init * q[:3])
-    dy_init = -(P[:3, :3] @ dp + P[:3, 3:] @ o + q[:3])
     dx = np.zeros(n)
-    dx[p.ip(0):p.ip(0) + 3] = dp
-    if free_T:
-        dx[iT] = dT
     dy_dyn = np.zeros((N, 3))
-    uprev = np.zeros(2)
-    for k in range(N):
+    if m_split == 0:
+        # stage 0: u_prev step is zero (u_{-1} = u0 is data); soft initial condition; then dT
+        Pt, qt, Mi0, piv = soft_min(P, q, E_init)
+        if np.any(piv <= 0):
+            ok = False
+        phat0 = -gh_init
+        dT = 0.0
+        if free_T:
+            if Pt[5, 5] <= 0:
+                ok = False
+            dT = -(qt[5] + Pt[5, :3] @ phat0) / Pt[5, 5]
+        o = np.array([0.0, 0.0, dT])
+        dp = Mi0.T @ (phat0 - E_init * (P[:3, 3:] @ o) - E_init * q[:3])
+        dy_init = -(P[:3, :3] @ dp + P[:3, 3:] @ o + q[:3])
+        uprev = np.zeros(2)
+    else:
+        # ---- forward half: cost-to-arrive W_k(xi) = 1/2 xi' Pi xi + pi' xi over xi = (dp_k, du_{k-1}, dT) -------------
+        # s = (dp(0:3), du_prev(3:5), dT(5), du(6:8), dp'(8:11)); eliminated: (dp, du_prev) -- at stage 0 only dp
+        Pi = np.zeros((6, 6))
+        pi = np.zeros(6)
+        D0 = 1.0 / E_init
+        Pi[:3, :3] = np.diag(D0)
+        pi[:3] = D0 * gh_init                   # 1/2 (dp + gh)' D0 (dp + gh)
+        fw = [None] * m_split
+        for k in range(m_split):
+            F, G, f, Lxx, Lxu, Luu, lx, lu = stage_blocks(k)
+            Q = np.zeros((11, 11))
+            c = np.zeros(11)
+            Q[:6, :6] = Pi + Lxx
+            Q[:6, 6:8] = Lxu
+            Q[6:8, :6] = Lxu.T
+            Q[6:8, 6:8] = Luu
+            c[:6] = pi + lx
+            c[6:8] = lu
+            Rr = np.zeros((3, 11))                # residual p' - A p - tcol T - B u + gh
+            Rr[:, 0:3] = -F[:3, :3]
+            Rr[:, 5] = -F[:3, 5]
+            Rr[:, 6:8] = -G[:3]
+            Rr[:, 8:11] = np.eye(3)
+            Dk = 1.0 / E_dyn[k]
+            Q += Rr.T @ (Dk[:, None] * Rr)
+            c += Rr.T @ (Dk * gh_dyn[k])
+            v = [0, 1, 2] if k == 0 else [0, 1, 2, 3, 4]
+            w = [8, 9, 10, 6, 7, 5]              # (dp', du' = du, dT): the next stage's xi
+            Lv, dv = ldl_nopivot(Q[np.ix_(v, v)])
+            if np.any(dv <= 0):
+                ok = False
+            Qvw = Q[np.ix_(v, w)]
+            Z = ldl_solve(Lv, dv, np.column_stack([Qvw, c[v]]))
+            fw[k] = (v, Z)                        # v* = -(Z[:, :6] w + Z[:, 6])
+            Pi = Q[np.ix_(w, w)] - Qvw.T @ Z[:, :6]
+            Pi = 0.5 * (Pi + Pi.T)
+            pi = c[w] - Qvw.T @ Z[:, 6]
+        # ---- the two halves meet at stage m
+        Lm, dm = ldl_nopivot(Pi + P)
+        if np.any(dm <= 0):
+            ok = False
+        xi_m = -ldl_solve(Lm, dm, pi + q)
+        if not free_T:
+            pass                                  # Lxx[5,5] = 1 at stage 0 and no coupling: dT comes out as 0
+        dT = xi_m[5]
+        if free_T:
+            dx[iT] = dT
+        # forward half recovered backwards; costates of the elastic rows from the cost-to-arrive
+        xi_next = xi_m.copy()
+        Pis, pis = Pi, pi
+        # (the cost-to-arrive of every stage is needed for the costates: recompute them on the way -- the blueprint keeps it simple)
+        Pi_list = []
+        Pi2 = np.zeros((6, 6)); pi2 = np.zeros(6)
+        Pi2[:3, :3] = np.diag(D0); pi2[:3] = D0 * gh_init
+        for k in range(m_split):
+            F, G, f, Lxx, Lxu, Luu, lx, lu = stage_blocks(k)
+            Q = np.zeros((11, 11)); c = np.zeros(11)
+            Q[:6, :6] = Pi2 + Lxx; Q[:6, 6:8] = Lxu; Q[6:8, :6] = Lxu.T; Q[6:8, 6:8] = Luu
+            c[:6] = pi2 + lx; c[6:8] = lu
+            Rr = np.zeros((3, 11)); Rr[:, 0:3] = -F[:3, :3]; Rr[:, 5] = -F[:3, 5]; Rr[:, 6:8] = -G[:3]; Rr[:, 8:11] = np.eye(3)
+            Dk = 1.0 / E_dyn[k]
+            Q += Rr.T @ (Dk[:, None] * Rr); c += Rr.T @ (Dk * gh_dyn[k])
+            v, Z = fw[k]
+            w = [8, 9, 10, 6, 7, 5]
+            Qvw = Q[np.ix_(v, w)]
+            Pi2 = Q[np.ix_(w, w)] - Qvw.T @ Z[:, :6]; Pi2 = 0.5 * (Pi2 + Pi2.T)
+            pi2 = c[w] - Qvw.T @ Z[:, 6]
+            Pi_list.append((Pi2.copy(), pi2.copy()))
+        for k in range(m_split - 1, -1, -1):
+            v, Z = fw[k]
+            vs = -(Z[:, :6] @ xi_next + Z[:, 6])
+            Pk1, pk1 = Pi_list[k]
+            dy_dyn[k] = (Pk1 @ xi_next + pk1)[:3]
+            dx[p.ip(k + 1):p.ip(k + 1) + 3] = xi_next[:3]
+            dx[p.iu(k):p.iu(k) + 2] = xi_next[3:5]
+            xi_k = np.zeros(6)
+            xi_k[:len(vs)] = vs
+            xi_k[5] = dT
+            xi_next = xi_k
+        dx[p.ip(0):p.ip(0) + 3] = xi_next[:3]
+        dy_init = D0 * (xi_next[:3] + gh_init)
+        dp, uprev = xi_m[:3].copy(), xi_m[3:5].copy()
+    if m_split == 0:
+        dx[p.ip(0):p.ip(0) + 3] = dp
+        if free_T:
+            dx[iT] = dT
+    for k in range(m_split, N):
         Kg, kap, Mi, Pn1, qn1, F, G, f = gains[k]
         xi = np.concatenate([dp, uprev, [dT]])
         u = Kg @ xi + kap

@@ -9,7 +9,7 @@ from oracle.kkt_structured import structured_step
 from tests.test_oracle_nlp import build
 
 
-def compare(p, d):
+def compare(p, d, split=0):
     n, N = p.n, p.N
     lay = [p.eq_layout()[i] for i in d["term"]]          # elastic equality rows, dense order
     Je, E, gh, iseq = d["Je"], d["E"], d["ghat"], d["iseq"]
@@ -30,7 +30,7 @@ def compare(p, d):
     tcol = [(-Je[rows][:, p.iT()] if free_T else np.zeros(3)) for rows in dyn_rows]
     dx, dnu, dyi, dyd, ok = structured_step(p, H, b, d["Jh"], d["ch"], A, B, tcol,
                                             [E[rows] for rows in dyn_rows], [gh[rows] for rows in dyn_rows],
-                                            E[init_rows], gh[init_rows], free_T)
+                                            E[init_rows], gh[init_rows], free_T, split=split)
     assert ok
     sc = max(1.0, np.max(np.abs(d["dx"])))
     np.testing.assert_allclose(dx, d["dx"], rtol=0, atol=2e-7 * sc)
@@ -53,3 +53,20 @@ def test_structured_equals_dense(nlp_golden, idx):
 
     ipm_dense.solve(p, dict(probe=probe, max_iter=41, max_soc=0))
     assert len(seen) >= 5
+
+
+@pytest.mark.parametrize("idx", [0, 1, 4, 5, 6])
+def test_two_sided_sweep_equals_dense(nlp_golden, idx):
+    """blueprint of the parallel Riccati: backward recursion from N to m, forward recursion (cost-to-arrive) from 0 to m,
+    one 6x6 solve where they meet -- same step as the dense augmented solve for every split stage"""
+    p = build(nlp_golden[idx])
+    seen = []
+
+    def probe(d):
+        if d["it"] in (0, 5, 25):
+            for m in range(1, p.N):
+                compare(p, d, split=m)
+            seen.append(d["it"])
+
+    ipm_dense.solve(p, dict(probe=probe, max_iter=26, max_soc=0))
+    assert len(seen) == 3
