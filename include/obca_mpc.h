@@ -154,11 +154,21 @@ int obca_set_certificate_buffers(obca_handle* h, double* z, double* y);
  * Returns OBCA_E_LDS if mode 1 / 3 / 4 cannot hold the shape. */
 int obca_set_mode(obca_handle* h, int mode);
 
+/* Four-wavefront kernels (OBCA_MODE 3, and auto mode for shapes whose rows do not fit one wavefront's registers): the
+ * Riccati sweep over the stages can be cut at stage ~0.45 N into a backward half (cost-to-go) and a forward half
+ * (cost-to-arrive) that two wavefronts run at the same time, meeting in one 6 x 6 solve.  Same Newton step up to
+ * roundoff (measured in the kernel: 1e-11..1e-10 of the step's size typically); the one-sided sweep rounds exactly like
+ * the one-wavefront kernels.  on = -1 (default): two-sided exactly where the one-wavefront kernels cannot run the
+ * shape, so that every shape both kernel families can run gives bit-identical results in both; 0: never; 1: always.
+ * Environment override at obca_create: OBCA_TWO_SIDED=-1|0|1. */
+int obca_set_two_sided_sweep(obca_handle* h, int on);
+
 /* Diagnostic: device buffer [max_batch,20] receiving per-phase shader-clock totals of each instance.
  * Only builds compiled with -DOBCA_PROFILE write to it; NULL (the default) disables it. */
 void obca_set_profile_buffer(obca_handle* h, double* prof);
 
-/* bytes of LDS one instance needs in the wave-per-instance kernel (> 163840: only the lane kernel runs it) */
+/* bytes of LDS one instance needs in the wave-per-instance kernels (> 163840: only the lane kernel runs it); the
+ * four-wavefront kernels ask for 8 * (36 * ((N + 1) / 2) + 42) bytes more (forward half of their two-sided Riccati sweep) */
 int64_t obca_lds_bytes(const obca_dims* dims);
 
 /* ------------------------------------------------------------------------------------------------------

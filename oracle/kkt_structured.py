@@ -76,7 +76,7 @@ def soft_min(P, q, E):
     return Pt, qt, Mi, piv
 
 
-def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_init, free_T, split=0):
+def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_init, free_T, split=0, kernel_check=None):
     """
     H, b     dense condensed Hessian / gradient in x-space (blocks are read out of it)
     Jrot     dense Jacobian of the hard rotation rows (rows ordered k-major, i, 2), crot residuals
@@ -239,6 +239,9 @@ def structured_step(p, H, b, Jrot, crot, A, B, tcol, E_dyn, gh_dyn, E_init, gh_i
             Qvw = Q[np.ix_(v, w)]
             Z = ldl_solve(Lv, dv, np.column_stack([Qvw, c[v]]))
             fw[k] = (v, Z)                        # v* = -(Z[:, :6] w + Z[:, 6])
+            if kernel_check is not None:
+                kernel_check(k, Pi, pi, F, G, Lxx, Lxu, Luu, lx, lu, Dk, gh_dyn[k], Z,
+                             Q[np.ix_(w, w)] - Qvw.T @ Z[:, :6], c[w] - Qvw.T @ Z[:, 6])
             Pi = Q[np.ix_(w, w)] - Qvw.T @ Z[:, :6]
             Pi = 0.5 * (Pi + Pi.T)
             pi = c[w] - Qvw.T @ Z[:, 6]

@@ -22,7 +22,8 @@ struct obca_handle {
     obca_dims dims;
     int32_t M, n_max, R_max, inst_off;
     int32_t offm[OBCA_MAX_OBST + 1];
-    int64_t lds_bytes;
+    int two_sided;                     // -1: where only the four-wavefront kernels fit (default), 0: never, 1: always
+    int64_t lds_bytes, lds_bytes_mw;   // one-wavefront kernels; four-wavefront kernels (+ the two-sided sweep's storage)
     double* prof;
     int mode;                 /* 0 auto, 1 wave-per-instance (LDS), 2 lane-per-instance (HBM workspace), 3 four waves per instance */
     bool wave_ok;             /* the one-wavefront LDS kernel can hold this shape */
@@ -101,15 +102,16 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
         h->offm[i + 1] = h->M;
     }
     h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
+    h->lds_bytes_mw = h->lds_bytes + 8 * OBCA_ZK_DOUBLES(d->N);
     h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
-    h->mw_ok = !(h->lds_bytes + 64 > 160 * 1024 || h->R_max > 1280); // 256 threads x 3 or 5 rows; 32 B of static LDS
+    h->mw_ok = !(h->lds_bytes_mw + 64 > 160 * 1024 || h->R_max > 1280); // 256 threads x 3 or 5 rows; 32 B of static LDS
     ObcaDeviceGuard guard(d->device);
     if (!guard.ok) { delete h; return OBCA_E_HIP; }
     // a kernel whose LDS request the runtime refuses is simply not offered (the lane kernel serves every shape)
-    if (h->mw_ok && h->lds_bytes > 64 * 1024 &&
+    if (h->mw_ok && h->lds_bytes_mw > 64 * 1024 &&
         hipFuncSetAttribute(h->R_max <= 768 ? reinterpret_cast<const void*>(obca_ipm_kernel_mw_r3)
                                             : reinterpret_cast<const void*>(obca_ipm_kernel_mw_r5),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_mw) != hipSuccess) {
         (void)hipGetLastError();
         h->mw_ok = false;
     }
@@ -123,6 +125,8 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
         }
     }
     h->mode = 0;
+    h->two_sided = -1;
+    if (const char* e = getenv("OBCA_TWO_SIDED")) { const int v = atoi(e); if (v >= -1 && v <= 1) h->two_sided = v; }
     if (const char* e = getenv("OBCA_MODE")) {
         const int m = atoi(e);                                     // out of range or not available for this shape: auto
         if (m >= 0 && m <= 4 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok) && !(m == 4 && !(h->wave_ok && h->R_max <= 384))) h->mode = m;
@@ -188,6 +192,12 @@ extern "C" int obca_set_certificate_buffers(obca_handle* h, double* z, double* y
     return OBCA_OK;
 }
 
+extern "C" int obca_set_two_sided_sweep(obca_handle* h, int on) {
+    if (!h || on < -1 || on > 1) return OBCA_E_INVAL;
+    h->two_sided = on;
+    return OBCA_OK;
+}
+
 extern "C" void obca_set_profile_buffer(obca_handle* h, double* prof) { if (h) h->prof = prof; }
 
 int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
@@ -203,6 +213,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     ObcaLaunch& L = *out;
     memset(&L, 0, sizeof(L));
     L.B = B; L.N = h->dims.N; L.nO = h->dims.n_obs; L.M = h->M; L.n_max = h->n_max; L.R_max = h->R_max; L.inst_off = h->inst_off;
+    L.two_sided = h->two_sided < 0 ? (h->wave_ok ? 0 : 1) : h->two_sided;
     for (int i = 0; i <= OBCA_MAX_OBST; ++i) L.offm[i] = h->offm[i];
     L.variant = variant; L.x0 = x0; L.u0 = u0; L.xref = xref; L.A = A; L.b = b; L.Ts = Ts; L.term = term;
     L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info; L.prof = h->prof;
@@ -277,7 +288,7 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
         L2.prm.opt.rho *= OBCA_RHO_ESCALATION;
         if (mw)
             hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
-                               (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
+                               (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2);
         else if (h->R_max <= 256)
             hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
         else if (h->R_max <= 320)

@@ -49,6 +49,7 @@
 #define OBCA_FILTER_CAP(R_max) ((R_max) <= 384 ? 64 : 128)
 
 #define OBCA_INST_DOUBLES 64   /* LDS reserved for the per-instance constant block (struct Inst) */
+#define OBCA_ZK_DOUBLES(N) (36 * (((N) + 1) / 2) + 42)   /* four-wavefront kernels: forward half of the two-sided Riccati sweep */
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
 struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc; };
@@ -61,6 +62,7 @@ struct ObcaParamsDev {
 
 struct ObcaLaunch {
     int32_t B, N, nO, M, n_max, R_max, inst_off;
+    int32_t two_sided;     /* four-wavefront kernels: Riccati sweep cut in two halves run by two wavefronts (obca_set_two_sided_sweep) */
     int32_t offm[OBCA_MAX_OBST + 1];
     const int32_t* variant;
     const double *x0, *u0, *xref, *A, *b, *Ts, *term;

@@ -141,6 +141,7 @@ struct Sh {
     double *Lall, *lall, *Sloc, *Y;
     double *Pk, *qk, *Kk, *kapk, *Mik;
     double *FG, *Mall, *mall;
+    double *Zk, *Pi0;                        // forward half of the two-sided sweep (four-wavefront kernels)
     double* lsv;                             // line-search scalars parked in LDS across a corrected (second-order) solve
     int* offm;
 };
@@ -1183,16 +1184,189 @@ __device__ __forceinline__ double fg_entry(const Lay& L, const Sh& S, const Inst
     return v;
 }
 
+// ---------------------------------------------------------------- two-sided sweep (four-wavefront kernels)
+// With four wavefronts per instance the serial sweep was the first wavefront's job alone (68 % of the time at N = 20).
+// The stage chain is cut at stage m = N/2: the first wavefront runs the backward recursion from stage N down to m
+// (cost-to-go P_m, q_m), the SECOND wavefront runs at the same time a forward recursion from stage 0 up to m: the
+// cost-to-arrive  W_k(xi) = 1/2 xi' Pi_k xi + pi_k' xi  over xi = (dp_k, du_{k-1}, dT), stages 0..k-1 minimised out.  One
+// forward stage eliminates v = (dp_k, du_{k-1}) (5 x 5 LDL^T; at stage 0 du_{-1} = 0 and only dp_0) from
+//   W_k + stage block + 1/2 |dp_{k+1} - [F G]_p (xi_k, du_k) + ghat|^2_{E^-1}
+// and lands on (dp_{k+1}, du_k, dT) = xi_{k+1}.  The halves meet in one 6 x 6 solve (Pi_m + P_m) xi_m = -(pi_m + q_m) and
+// are recovered outwards at the same time.  Inertia test as before, by additivity: every eliminated block positive
+// definite.  Blueprint and its check against the dense solve: oracle/kkt_structured.py (split > 0),
+// tests/test_kkt_structured.py.  Each wavefront only reads what it wrote itself until the halves meet, so the stages
+// are separated by wavefront-level fences (LDS operations of one wavefront complete in order), not workgroup barriers.
+#if OBCA_NT == 256
+#ifndef OBCA_TWO_SIDED_DMAX
+#define OBCA_TWO_SIDED_DMAX 1.0e6
+#endif
+#ifndef OBCA_SPLIT_NUM      /* the halves meet at stage m = N * NUM / 20: a forward stage (5 x 5 elimination) costs about 1.2 backward stages */
+#define OBCA_SPLIT_NUM 9
+#endif
+#define WSYNC() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// LDL^T without pivoting of a packed lower triangle (entry (i, j), i >= j, at i (i + 1) / 2 + j), in place: unit factor
+// below the diagonal, reciprocal pivots in id.  Returns 1 on a non-positive pivot.
+template <int n>
+__device__ __forceinline__ int ldl_factor(double* s, double* id) {
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        const double d = s[j * (j + 1) / 2 + j];
+        bad |= !(d > 0.0);
+        id[j] = 1.0 / d;
+        double c[n];
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) c[i] = s[i * (i + 1) / 2 + j];
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) {
+            const double l = c[i] * id[j];
+            s[i * (i + 1) / 2 + j] = l;
+#pragma unroll
+            for (int t = j + 1; t <= i; ++t) s[i * (i + 1) / 2 + t] = fma(-l, c[t], s[i * (i + 1) / 2 + t]);
+        }
+    }
+    return bad;
+}
+template <int n>
+__device__ __forceinline__ void ldl_solve(const double* s, const double* id, double* y) {
+#pragma unroll
+    for (int j = 0; j < n; ++j)
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) y[i] = fma(-s[i * (i + 1) / 2 + j], y[j], y[i]);
+#pragma unroll
+    for (int j = 0; j < n; ++j) y[j] *= id[j];
+#pragma unroll
+    for (int j = n - 1; j >= 0; --j)
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) y[j] = fma(-s[i * (i + 1) / 2 + j], y[i], y[j]);
+}
+__device__ __forceinline__ double sym6(const double* P, int a, int b) { return a >= b ? P[6 * a + b] : P[6 * b + a]; }
+
+// Forward half, run by ONE wavefront (lane = 0..63 within it).  Pi_{k+1}, pi_{k+1} go to slot k of Pk / qk (the backward
+// half uses the slots m..N), the recovery map v = -(Z (xi_{k+1}; 1)) of stage k to Zk + 36 k (column c at 5 c).
+// Lane (a, b) of the first 36 produces entry (a, b) of Pi_{k+1}, lanes 36..41 entry a of pi_{k+1}; every lane factors the
+// stage's 5 x 5 block itself (redundant arithmetic is free here, a round trip through LDS is not).
+__device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, int lane, int m) {
+    const double* xv = S.x;
+    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double h = T * in.Ts;
+    int bad = 0;
+    if (lane < 42) {            // cost-to-arrive at stage 0: the elastic initial condition 1/2 |dp_0 + ghat|^2_{E^-1}
+        double v = 0.0;
+        if (lane < 36) { const int a = lane / 6, b = lane - 6 * a; if (a == b && a < 3) v = S.Einv[L.r_init + a]; }
+        else { const int a = lane - 36; if (a < 3) v = S.Einv[L.r_init + a] * S.gh[L.r_init + a]; }
+        S.Pi0[lane] = v;
+    }
+    WSYNC();
+    const int a = lane < 36 ? lane / 6 : (lane < 42 ? lane - 36 : 0);       // row: index into w = (dp'(0:3), du(3:5), dT(5))
+    const int b = lane < 36 ? lane - 6 * (lane / 6) : 6;                    // column of w, or 6: the gradient
+    for (int k = 0; k < m; ++k) {
+        const double* Pi = k == 0 ? S.Pi0 : S.Pk + 36 * (k - 1);
+        const double* pi = k == 0 ? S.Pi0 + 36 : S.qk + 6 * (k - 1);
+        const double* Lk = S.Lall + 36 * k;         // over z = (dp(0:3), du_prev(3:5), dT(5), du(6:8)), packed like s below
+        const double* lk = S.lall + 8 * k;
+        double D[3], gh[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { D[j] = S.Einv[L.r_dyn + 3 * k + j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
+        const double cs = S.ct[k], sn = S.st[k], u0 = xv[L.iu(k)], u1 = xv[L.iu(k) + 1];
+        const double a02 = -h * u0 * sn, a12 = h * u0 * cs;         // d pose' / d theta: A = I + a02 e0 e2' + a12 e1 e2'
+        double tc[3] = {0.0, 0.0, 0.0};
+        if (L.free_T) { tc[0] = in.Ts * u0 * cs; tc[1] = in.Ts * u0 * sn; tc[2] = in.Ts * u1; }
+        // ---- the eliminated block  S_vv = Pi_vv + L_vv + A' E^-1 A
+        double s[15], id[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int l = 0; l <= j; ++l) s[j * (j + 1) / 2 + l] = Pi[6 * j + l] + Lk[j * (j + 1) / 2 + l];
+        s[0] += D[0];
+        s[2] += D[1];
+        s[3] = fma(a02, D[0], s[3]);
+        s[4] = fma(a12, D[1], s[4]);
+        s[5] += fma(a02 * a02, D[0], fma(a12 * a12, D[1], D[2]));
+        if (k == 0) {           // du_{-1} is data: rows 3, 4 leave the system
+            s[6] = 0.0; s[7] = 0.0; s[8] = 0.0; s[9] = 1.0; s[10] = 0.0; s[11] = 0.0; s[12] = 0.0; s[13] = 0.0; s[14] = 1.0;
+        }
+        bad |= ldl_factor<5>(s, id);
+        // ---- columns a and b of [S_vw c_v]: r = m + A' E^-1 f, f the column's coefficient in the dynamics residual
+        // (dp'_c: -e_c;  du_c: B e_c;  dT: the T column;  gradient: -ghat), m its entries in Pi + stage block
+        double fa[3], fb[3], ra[5], rb[5];
+        auto column = [&](int c, double* f, double* r) {
+            const int zi = c < 5 ? 3 + c : 5;           // (c = 3, 4 -> z index 6, 7;  c = 5 -> 5)
+            f[0] = c < 3 ? (c == 0 ? -1.0 : 0.0) : c == 3 ? h * cs : c == 4 ? 0.0 : c == 5 ? tc[0] : -gh[0];
+            f[1] = c < 3 ? (c == 1 ? -1.0 : 0.0) : c == 3 ? h * sn : c == 4 ? 0.0 : c == 5 ? tc[1] : -gh[1];
+            f[2] = c < 3 ? (c == 2 ? -1.0 : 0.0) : c == 3 ? 0.0 : c == 4 ? h : c == 5 ? tc[2] : -gh[2];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                double v = 0.0;
+                if (c >= 3) v = c == 6 ? lk[j] : Lk[zi * (zi + 1) / 2 + j];
+                if (c >= 5) v += c == 6 ? pi[j] : Pi[30 + j];
+                r[j] = v;
+            }
+            const double g0 = D[0] * f[0], g1 = D[1] * f[1], g2 = D[2] * f[2];
+            r[0] += g0;
+            r[1] += g1;
+            r[2] += fma(a02, g0, fma(a12, g1, g2));
+            if (k == 0) { r[3] = 0.0; r[4] = 0.0; }
+        };
+        column(a, fa, ra);
+        column(b, fb, rb);
+        // entry (a, b) of [S_ww c_w]
+        double out = fma(fa[0] * D[0], fb[0], fma(fa[1] * D[1], fb[1], fa[2] * D[2] * fb[2]));
+        if (a >= 3 && b >= 3) {
+            const int za = a < 5 ? 3 + a : 5, zb = b < 5 ? 3 + b : 5;
+            if (b < 6) {
+                out += Lk[LS(za, zb)];
+                if (a == 5 && b == 5) out += Pi[35];
+            } else {
+                out += lk[za];
+                if (a == 5) out += pi[5];
+            }
+        }
+        ldl_solve<5>(s, id, rb);                    // rb: column b of Z = S_vv^-1 [S_vw c_v]
+#pragma unroll
+        for (int j = 0; j < 5; ++j) out = fma(-ra[j], rb[j], out);
+        if (lane < 36) S.Pk[36 * k + lane] = out;
+        else if (lane < 42) S.qk[6 * k + a] = out;
+        if (a == 0 && lane < 42) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) S.Zk[36 * k + 5 * b + j] = rb[j];
+        }
+        WSYNC();
+        if (__any(bad)) break;
+    }
+    return bad;
+}
+#endif
+
 // ---------------------------------------------------------------- level 2: Riccati sweep + forward pass
 // Two LDS round trips per stage: (A) every lane rebuilds P~ in registers and produces ONE entry of the 8x8
 // stage matrix Mall = Lall + [F G]' P~ [F G]; (B) every lane inverts the 2x2 input block and produces one entry
 // of P_k / q_k / K.  Returns 1 on a wrong-sign pivot; on success dx (poses, inputs, T) and the multiplier steps
 // of the soft rows are written.
+#if OBCA_NT == 256
+// Stage where the two halves of the sweep meet (0: one-sided sweep).  The forward half carries the elastic rows in
+// information form (E^-1 enters its blocks), which loses digits to cancellation once E^-1 is huge (the last few
+// iterations, when the elastic variables vanish: E ~ 1e-10 and below); the backward half's (I + P E)^-1 form does not.
+// Measured on the blueprint (oracle/kkt_structured.py): step error <= 1e-11 relative while E >= 1e-6, up to 1e-8 below;
+// in the kernel itself (-DOBCA_PROFILE -DOBCA_TWO_SIDED_CHECK: every two-sided solve repeated one-sided): see DESIGN.md.
+// So the two-sided sweep serves the iterations with max E^-1 <= OBCA_TWO_SIDED_DMAX -- nine in ten -- and the others
+// run one-sided.  (Every wavefront evaluates the test itself: same data, same result, no barrier.)
+__device__ __forceinline__ int two_sided_split(const Lay& L, const Sh& S, int lane) {
+    int m = L.N >= 4 ? L.N * OBCA_SPLIT_NUM / 20 : 0;
+    if (m > 0) {
+        double dmax = 0.0;
+        for (int r = L.r_init + (lane & 63); r < L.r_term; r += 64) dmax = fmax(dmax, S.Einv[r]);
+        if (wave_max(dmax) > OBCA_TWO_SIDED_DMAX) m = 0;
+    }
+    return m;
+}
+#endif
 #ifdef OBCA_PROFILE
-__device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, long long* prof_t) {
+__device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, long long* prof_t, bool allow_two = true) {
     long long rlast = wall_clock64();
 #else
-__device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
+__device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool allow_two = true) {
 #endif
 #ifdef NO_RICCATI
     return 0;
@@ -1201,6 +1375,14 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
     int bad = 0;
+#if OBCA_NT == 256
+#define RSYNC() WSYNC()
+    const int m = allow_two ? two_sided_split(L, S, lane) : 0;
+    if (lane < 64) {
+#else
+#define RSYNC() SYNC()
+    constexpr int m = 0;
+#endif
     // [F G] of the first stage of the sweep, and the terminal value function
     for (int t = lane; t < 48; t += NT) S.FG[t] = fg_entry(L, S, in, xv, h, L.N - 1, t);
     {
@@ -1214,9 +1396,9 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
             qN[a] = (a < 3) ? S.lall[8 * L.N + a] : 0.0;
         }
     }
-    SYNC();
+    RSYNC();
     RPROF(12)
-    for (int k = L.N - 1; k >= 0; --k) {
+    for (int k = L.N - 1; k >= m; --k) {
         // ---- phase A ----------------------------------------------------------------------------------
         // Entry (a, b) of Mall = Lall + [F G]' P~ [F G] WITHOUT forming P~ = soft-min of (P, E): with M = (I + Ppp E)^-1,
         //   P~ f = ( M (Ppp f_p + Ppo f_o) ,  Poo f_o + Pop E M (E^-1 f_p - Ppo f_o) )
@@ -1296,7 +1478,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
                 if (lane < 9) S.Mik[9 * k + lane] = fsel;
             }
         }
-        SYNC();
+        RSYNC();
         RPROF(13)
         // ---- phase B ----------------------------------------------------------------------------------
         if (NT == 64 || lane < 64) {
@@ -1320,21 +1502,33 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
             }
         }
         }
-        if (k > 0) {                        // phase A of this stage is over: its [F G] can make room for the next one
-            // (with four wavefronts the second one writes it: it has no entry of P_k to compute)
-            const int t = NT > 64 ? lane - 64 : lane;
+        if (k > m) {                        // phase A of this stage is over: its [F G] can make room for the next one
+            // (with two wavefronts the second one writes it: it has no entry of P_k to compute)
+            const int t = NT == 128 ? lane - 64 : lane;
             if (t >= 0 && t < 48) S.FG[t] = fg_entry(L, S, in, xv, h, k - 1, t);
         }
-        SYNC();
+        RSYNC();
         RPROF(14)
+#if OBCA_NT == 256
+        if (__any(bad)) break;
+#else
         if (red_or(bad)) return 1;         // wrong-sign pivot: the attempt is over, no need to finish the sweep
+#endif
     }
+#if OBCA_NT == 256
+    } else if (lane < 128 && m > 0) {
+        bad |= riccati_forward_half(L, S, in, lane - 64, m);
+    }
+    SYNC();                                 // the halves meet
+    if (red_or(bad)) return 1;
+#endif
     // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
     double E0[3], D0[3], g0[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { D0[j] = S.Einv[L.r_init + j]; E0[j] = 1.0 / D0[j]; g0[j] = S.gh[L.r_init + j]; }
     Lu3 lu0;
     double s1[3] = {0.0, 0.0, 0.0}, X55 = 1.0, qt5 = 0.0;
+    if (m == 0) {
     if (NT == 64 || lane < 64) {
         const double* P0 = S.Pk;
         const double* q0 = S.qk;
@@ -1350,11 +1544,73 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
     bad = red_or(bad);
     RPROF(15)
     if (bad) return 1;
+    }
+    double dT = 0.0;
+    double dp[3] = {0.0, 0.0, 0.0}, up[2] = {0.0, 0.0};
+#if OBCA_NT == 256
+    if (m > 0) {
+        // ---- the halves meet: (Pi_m + P_m) xi_m = -(pi_m + q_m), by the first two wavefronts (each for its own half)
+        double xi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (lane < 128) {
+            const double* Pb = S.Pk + 36 * m;          // cost-to-go of stage m
+            const double* Pf = S.Pk + 36 * (m - 1);    // cost-to-arrive at stage m
+            double sm[21], idm[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+#pragma unroll
+                for (int l = 0; l <= j; ++l) sm[j * (j + 1) / 2 + l] = Pf[6 * j + l] + 0.5 * (Pb[6 * j + l] + Pb[6 * l + j]);
+                xi[j] = -(S.qk[6 * (m - 1) + j] + S.qk[6 * m + j]);
+            }
+            bad |= ldl_factor<6>(sm, idm);
+            ldl_solve<6>(sm, idm, xi);
+        }
+        bad = red_or(bad);
+        RPROF(15)
+        if (bad) return 1;
+        dp[0] = xi[0]; dp[1] = xi[1]; dp[2] = xi[2]; up[0] = xi[3]; up[1] = xi[4]; dT = xi[5];
+        if (lane >= 64 && lane < 128) {
+            // ---- forward half recovered downwards by the second wavefront: (dp_k, du_{k-1}) = -Z_k (xi_{k+1}; 1); the
+            // multiplier steps of the elastic dynamics rows are the gradient of the cost-to-arrive
+            const bool w0 = lane == 64;
+            if (w0) {
+                S.dx[L.ip(m)] = xi[0]; S.dx[L.ip(m) + 1] = xi[1]; S.dx[L.ip(m) + 2] = xi[2];
+                S.dx[L.iu(m - 1)] = xi[3]; S.dx[L.iu(m - 1) + 1] = xi[4];
+                if (L.free_T) S.dx[L.iT()] = dT;
+            }
+            for (int k = m - 1; k >= 0; --k) {
+                const double* Z = S.Zk + 36 * k;
+                double v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    double acc = Z[30 + j];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) acc = fma(Z[5 * c + j], xi[c], acc);
+                    v[j] = -acc;
+                }
+                if (w0) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        double acc = S.qk[6 * k + a];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) acc = fma(sym6(S.Pk + 36 * k, a, c), xi[c], acc);
+                        S.dy[L.r_dyn + 3 * k + a] = acc;
+                        S.dx[L.ip(k) + a] = v[a];
+                    }
+                    if (k > 0) { S.dx[L.iu(k - 1)] = v[3]; S.dx[L.iu(k - 1) + 1] = v[4]; }
+                }
+                xi[0] = v[0]; xi[1] = v[1]; xi[2] = v[2]; xi[3] = v[3]; xi[4] = v[4];
+            }
+            if (w0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) S.dy[L.r_init + a] = D0[a] * (xi[a] + g0[a]);
+            }
+        }
+    }
+#endif
     // ---- forward pass: every lane (of the first wavefront) carries the (tiny) state redundantly, lane 0 stores
     if (NT == 64 || lane < 64) {
-    double dT = 0.0;
+    if (m == 0) {
     if (L.free_T) dT = -(qt5 - dot3(s1[0], g0[0], s1[1], g0[1], s1[2], g0[2])) / X55;
-    double dp[3], up[2] = {0.0, 0.0};
     {
         const double* P0 = S.Pk;
         const double* q0 = S.qk;
@@ -1373,7 +1629,8 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane) {
         S.dx[0] = dp[0]; S.dx[1] = dp[1]; S.dx[2] = dp[2];
         if (L.free_T) S.dx[L.iT()] = dT;
     }
-    for (int k = 0; k < L.N; ++k) {
+    }
+    for (int k = m; k < L.N; ++k) {
         // all operands of the stage first (independent LDS reads, one wait), then the arithmetic
         double Kg[12], P1[18], Mi[9], q1[3], E[3], gh[3];
 #pragma unroll
@@ -1461,7 +1718,7 @@ template <bool FROM_MEMORY, class T> __device__ __forceinline__ T* uni(T* p) {
 }
 template <bool FROM_MEMORY> __device__ __forceinline__ double uni(double v) { return FROM_MEMORY ? lane_read(v, 0) : v; }
 struct ObcaHead {
-    int32_t B, N, nO, M, n_max, R_max, inst_off;
+    int32_t B, N, nO, M, n_max, R_max, inst_off, two_sided;
     const int32_t* variant;
     const double *x0, *u0, *xref, *A, *b, *Ts, *term;
     double *xopt, *uopt, *ts_opt;
@@ -1482,7 +1739,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     {
         constexpr bool U = FROM_MEMORY;
         A.B = uni<U>(Ain.B); A.N = uni<U>(Ain.N); A.nO = uni<U>(Ain.nO); A.M = uni<U>(Ain.M); A.n_max = uni<U>(Ain.n_max);
-        A.R_max = uni<U>(Ain.R_max); A.inst_off = uni<U>(Ain.inst_off);
+        A.R_max = uni<U>(Ain.R_max); A.inst_off = uni<U>(Ain.inst_off); A.two_sided = uni<U>(Ain.two_sided);
         A.variant = uni<U>(Ain.variant); A.x0 = uni<U>(Ain.x0); A.u0 = uni<U>(Ain.u0); A.xref = uni<U>(Ain.xref); A.A = uni<U>(Ain.A);
         A.b = uni<U>(Ain.b); A.Ts = uni<U>(Ain.Ts); A.term = uni<U>(Ain.term); A.xopt = uni<U>(Ain.xopt); A.uopt = uni<U>(Ain.uopt);
         A.ts_opt = uni<U>(Ain.ts_opt); A.status = uni<U>(Ain.status); A.iters = uni<U>(Ain.iters); A.info = uni<U>(Ain.info);
@@ -1555,6 +1812,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
     }
     Inst& in = *reinterpret_cast<Inst*>(smem + A.inst_off);
+    // two-sided sweep (four-wavefront kernels only: their launches ask for OBCA_ZK_DOUBLES(N) more LDS, BEHIND everything the
+    // other kernels carve, so that one layout serves all): recovery maps of the forward half, cost-to-arrive at stage 0
+    S.Zk = smem + A.inst_off + OBCA_INST_DOUBLES; S.Pi0 = S.Zk + 36 * ((L.N + 1) / 2);
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i <= OBCA_MAX_OBST; ++i) S.offm[i] = Ain.offm[i];     // static indices: A stays in kernarg
@@ -1831,9 +2091,37 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             int bad = local_blocks(L, S, in, delta_w, lane);
             PROF(4)
 #ifdef OBCA_PROFILE
-            if (!bad) bad = riccati(L, S, in, lane, prof_t);
+            if (!bad) bad = riccati(L, S, in, lane, prof_t, A.two_sided != 0);
+#if defined(OBCA_TWO_SIDED_CHECK) && OBCA_NT == 256
+            // dev check: every two-sided solve is repeated one-sided on the same data; slot 18 keeps the largest
+            // difference of the steps (poses, inputs, T; relative to the step's largest entry, x 1e18), slot 19 that of
+            // the multiplier steps of the elastic rows
+            if (!bad && A.two_sided != 0 && two_sided_split(L, S, lane) > 0) {
+                const int nsave = 5 * L.N + 3 + 1, nrow = L.r_term;
+                for (int t = lane; t < nsave + nrow; t += NT) {
+                    double v;
+                    if (t < nsave) { const int k = t / 5, j = t - 5 * k; v = (t == nsave - 1) ? (L.free_T ? S.dx[L.iT()] : 0.0) : (j < 3 ? S.dx[L.ip(k) + j] : S.dx[L.iu(k) + j - 3]); }
+                    else v = S.dy[t - nsave];
+                    S.Zk[t] = v;
+                }
+                SYNC();
+                (void)riccati(L, S, in, lane, prof_t, false);
+                double ex = 0.0, sx = 0.0, ey = 0.0, sy = 0.0;
+                for (int t = lane; t < nsave + nrow; t += NT) {
+                    double v;
+                    if (t < nsave) { const int k = t / 5, j = t - 5 * k; v = (t == nsave - 1) ? (L.free_T ? S.dx[L.iT()] : 0.0) : (j < 3 ? S.dx[L.ip(k) + j] : S.dx[L.iu(k) + j - 3]); }
+                    else v = S.dy[t - nsave];
+                    if (t < nsave) { ex = fmax(ex, fabs(v - S.Zk[t])); sx = fmax(sx, fabs(v)); }
+                    else { ey = fmax(ey, fabs(v - S.Zk[t])); sy = fmax(sy, fabs(v)); }
+                }
+                ex = red_max(ex); sx = red_max(sx); ey = red_max(ey); sy = red_max(sy);
+                const long long rx = (long long)(ex / fmax(sx, 1e-300) * 1e18), ry = (long long)(ey / fmax(sy, 1e-300) * 1e18);
+                if (rx > prof_t[18]) prof_t[18] = rx;
+                if (ry > prof_t[19]) prof_t[19] = ry;
+            }
+#endif
 #else
-            if (!bad) bad = riccati(L, S, in, lane);
+            if (!bad) bad = riccati(L, S, in, lane, A.two_sided != 0);
 #endif
             PROF(5)
             ++nfact;

@@ -94,6 +94,11 @@ class BatchSolver:
         'lane' (64 instances per wavefront, HBM workspace)"""
         _lib.check(self.lib.obca_set_mode(self._h, self.MODES.get(mode, mode)))
 
+    def set_two_sided_sweep(self, on):
+        """four-wavefront kernels: Riccati sweep as two concurrent halves (include/obca_mpc.h, obca_set_two_sided_sweep);
+        None / -1 = default (only where the one-wavefront kernels cannot run the shape), False / True = never / always"""
+        _lib.check(self.lib.obca_set_two_sided_sweep(self._h, -1 if on is None else int(on)))
+
     def enable_certificates(self, on=True):
         """Keep the final primal vector and multipliers of every solve (include/obca_mpc.h, obca_set_certificate_buffers):
         after a solve ``self.cert_z[:B]`` is [B, primal_size] and ``self.cert_y[:B]`` is [B, dual_size]."""
