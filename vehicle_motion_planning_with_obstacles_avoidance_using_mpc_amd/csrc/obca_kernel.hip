@@ -1309,9 +1309,11 @@ __device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, i
             r[2] += fma(a02, g0, fma(a12, g1, g2));
             if (k == 0) { r[3] = 0.0; r[4] = 0.0; }
         };
-        column(a, fa, ra);
+        // (column b first, through the solve; column a only afterwards, when the factor's registers are free again)
         column(b, fb, rb);
-        // entry (a, b) of [S_ww c_w]
+        ldl_solve<5>(s, id, rb);                    // rb: column b of Z = S_vv^-1 [S_vw c_v]
+        column(a, fa, ra);
+        // entry (a, b) of [S_ww c_w] - S_wv Z
         double out = fma(fa[0] * D[0], fb[0], fma(fa[1] * D[1], fb[1], fa[2] * D[2] * fb[2]));
         if (a >= 3 && b >= 3) {
             const int za = a < 5 ? 3 + a : 5, zb = b < 5 ? 3 + b : 5;
@@ -1323,7 +1325,6 @@ __device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, i
                 if (a == 5) out += pi[5];
             }
         }
-        ldl_solve<5>(s, id, rb);                    // rb: column b of Z = S_vv^-1 [S_vw c_v]
 #pragma unroll
         for (int j = 0; j < 5; ++j) out = fma(-ra[j], rb[j], out);
         if (lane < 36) S.Pk[36 * k + lane] = out;
@@ -2092,6 +2093,16 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             PROF(4)
 #ifdef OBCA_PROFILE
             if (!bad) bad = riccati(L, S, in, lane, prof_t, A.two_sided != 0);
+#if !defined(OBCA_TWO_SIDED_CHECK) && OBCA_NT == 256
+            if (A.two_sided != 0) {         // slots 18 / 19: solves whose sweep ran two-sided / all solves, and the largest E^-1 seen
+                double dmax = 0.0;
+                for (int r = L.r_init + (lane & 63); r < L.r_term; r += 64) dmax = fmax(dmax, S.Einv[r]);
+                dmax = wave_max(dmax);
+                prof_t[18] += (dmax <= OBCA_TWO_SIDED_DMAX) ? 1 : 0;
+                prof_t[19] += 1;
+                if (dmax <= 4e6 && dmax > 1e6) prof_t[10] += 1;
+            }
+#endif
 #if defined(OBCA_TWO_SIDED_CHECK) && OBCA_NT == 256
             // dev check: every two-sided solve is repeated one-sided on the same data; slot 18 keeps the largest
             // difference of the steps (poses, inputs, T; relative to the step's largest entry, x 1e18), slot 19 that of
