@@ -135,7 +135,8 @@ def config_c3(B, N=20):
     each; both run on the four-wavefront LDS kernel."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
-    res = {"workload": "C3 (SURVEY 8d): N=%d, B=%d unique seeded instances per sub-batch" % (N, B)}
+    res = {"workload": "C3 (SURVEY 8d): N=%d, B=%d unique seeded instances per sub-batch" % (N, B),
+           "kernel": "four wavefronts per instance, two-sided Riccati sweep (default for shapes beyond the one-wavefront kernels)"}
     procs = max(1, min(48, (os.cpu_count() or 1) // 2))
     for name, gated in (("free_time_obca_mpc4", False), ("gated_obca_mpc6", True)):
         b = sc.make_batch_c3(B, N, gated=gated, procs=procs)

@@ -66,7 +66,8 @@ def test_two_sided_sweep_gives_the_one_sided_answers():
     the same KKT system, so the same Newton steps up to roundoff (1e-11..1e-10 of the step, measured in the kernel) --
     same verdicts, same iteration counts on most instances, same plans to the accuracy the stopping test leaves"""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
-    for b, N, gated in ((sc.make_batch(128, 5), 5, False), (sc.make_batch_c3(64, 10, gated=False), 10, False),
+    for b, N, gated in ((sc.make_batch(128, 5), 5, False), (sc.make_batch(64, 4), 4, False),       # N = 4: forward half = stage 0 alone
+                        (sc.make_batch_c3(32, 7, gated=True), 7, True), (sc.make_batch_c3(64, 10, gated=False), 10, False),
                         (sc.make_batch_c3(48, 20, gated=False), 20, False), (sc.make_batch_c3(48, 20, gated=True), 20, True)):
         one, two = run(b, N, "multiwave", two_sided=False), run(b, N, "multiwave", two_sided=True)
         ok1, ok2 = np.isin(one["status"], (0, 1)), np.isin(two["status"], (0, 1))
