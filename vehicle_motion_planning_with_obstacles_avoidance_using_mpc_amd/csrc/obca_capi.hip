@@ -22,7 +22,6 @@ struct obca_handle {
     obca_dims dims;
     int32_t M, n_max, R_max, inst_off;
     int32_t offm[OBCA_MAX_OBST + 1];
-    int n_cu;                          // compute units of the handle's device
     int two_sided;                     // -1: where only the four-wavefront kernels fit (default), 0: never, 1: always
     int64_t lds_bytes, lds_bytes_mw;   // one-wavefront kernels; four-wavefront kernels (+ the two-sided sweep's storage)
     double* prof;
@@ -127,8 +126,6 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     }
     h->mode = 0;
     h->two_sided = -1;
-    h->n_cu = 0;
-    if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess) { (void)hipGetLastError(); h->n_cu = 0; }
     if (const char* e = getenv("OBCA_TWO_SIDED")) { const int v = atoi(e); if (v >= -1 && v <= 1) h->two_sided = v; }
     if (const char* e = getenv("OBCA_MODE")) {
         const int m = atoi(e);                                     // out of range or not available for this shape: auto
@@ -283,9 +280,10 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
             hipLaunchKernelGGL(obca_ipm_kernel_w2_r3, dim3(B), dim3(128), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
         return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
     }
-    // (a batch that leaves CUs idle -- B <= number of CUs -- also goes to the four-wavefront kernels in auto mode: one CU per
-    // instance, 1.3x shorter launch; with the default one-sided sweep the answers are bit-identical to the one-wavefront kernel's)
-    const bool mw = h->mode == 3 || (h->mode == 0 && h->mw_ok && (!h->wave_ok || B <= h->n_cu));
+    // (the choice depends on the SHAPE only, never on the batch size: the answer to an instance must not depend on how many
+    // neighbours it was submitted with.  Measured: four wavefronts per instance would shorten launches of B <= 256 by 10-12 %,
+    // tools/gpu_small_batch.py with OBCA_MODE=3 -- callers that want that latency ask for it, as the obca() class does)
+    const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw || !lane) {
         // the kernels run the escalated second solve of a free-time instance themselves, from their own descriptor
