@@ -1,0 +1,20 @@
+import sys, os, numpy as np, torch
+sys.path.insert(0,'.')
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
+w = pack_worlds([make_world_c5(i) for i in range(64)])
+outs=[]
+for mode, env in (("fused",None),("lockstep",None),("lockstep","3")):
+    if env: os.environ["OBCA_MODE"]=env
+    dr = DeviceRollouts(w, N=5); dr.set_mode(mode); dr.run(12)
+    outs.append({k: v.cpu().numpy() for k, v in dr.read().items()}); torch.cuda.synchronize()
+    os.environ.pop("OBCA_MODE",None)
+for j,name in ((1,"lockstep auto"),(2,"lockstep OBCA_MODE=3")):
+    for k in outs[0]:
+        a,b=outs[0][k],outs[j][k]
+        if not np.array_equal(a,b):
+            d=np.abs(a.astype(float)-b.astype(float))
+            bad=np.unique(np.argwhere(d>0)[:,0])
+            print(name,k,"differs on rollouts",bad[:10],"max",d.max())
+    print(name,"done")
+print("steps",outs[0]["steps"][:16], outs[2]["steps"][:16])
