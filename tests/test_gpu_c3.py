@@ -77,8 +77,9 @@ def test_two_sided_sweep_gives_the_one_sided_answers():
         assert same.sum() >= (0.25 if gated else 0.8) * both.sum()
         d = np.abs(one["xopt"] - two["xopt"]).reshape(len(both), -1).max(1)
         # both stop at the first iterate whose scaled KKT error is <= 1e-8; along flat directions that leaves ~1e-6 of room
-        # in x, which roundoff-different paths use
-        assert d[same].max() < 1e-5 and np.median(d[same]) < 1e-8
+        # in x, which roundoff-different paths use; on the non-convex fixed-time problems a path may also settle in another
+        # local optimum (then each plan must be valid on its own: dynamics below, certificates in test_gpu_certificates.py)
+        assert (d[both] < 1e-5).sum() >= (0.9 if gated else 1.0) * both.sum() and np.median(d[same]) < 1e-8
         for o in (one, two):
             assert dynamics_residual(o["xopt"], o["uopt"], o["ts_opt"])[both].max() < 1e-7
         assert np.array_equal(run(b, N, "multiwave", two_sided=True)["xopt"], two["xopt"])          # deterministic

@@ -1341,9 +1341,9 @@ __device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, i
 #endif
 
 // ---------------------------------------------------------------- level 2: Riccati sweep + forward pass
-// Two LDS round trips per stage: (A) every lane rebuilds P~ in registers and produces ONE entry of the 8x8
-// stage matrix Mall = Lall + [F G]' P~ [F G]; (B) every lane inverts the 2x2 input block and produces one entry
-// of P_k / q_k / K.  Returns 1 on a wrong-sign pivot; on success dx (poses, inputs, T) and the multiplier steps
+// Two LDS round trips per stage: (A) every lane applies P~ to ONE column and produces one entry of the lower triangle
+// of the symmetric 8x8 stage matrix Mall = Lall + [F G]' P~ [F G] (36 lanes) or of its gradient (8 lanes, same expression);
+// (B) every lane inverts the 2x2 input block and produces one entry of P_k / q_k / K.  Returns 1 on a wrong-sign pivot; on success dx (poses, inputs, T) and the multiplier steps
 // of the soft rows are written.
 #if OBCA_NT == 256
 // Stage where the two halves of the sweep meet (0: one-sided sweep).  The forward half carries the elastic rows in
@@ -1419,16 +1419,27 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
             for (int i = 0; i < 18; ++i) Pa[i] = Pl[i];
             Lu3 lu;
             bad |= lu3_factor(Pa, 6, E, lu);
-            const int a = lane >> 3, b = lane & 7;
+            // lanes 0..35: entry (a, b), a >= b, of the SYMMETRIC stage matrix (packed like the stage blocks: lane = LS(a, b));
+            // lanes 36..43: entry a of its gradient, computed by the same expression: with f = (-ghat, 0) as the "column",
+            //   lall + [F G]' (q~ - P~ (ghat, 0)) = lall + [F G]' (P~ f + q~),   q~ = (M q_p, q_o - Pop E M q_p),
+            // i.e. q_p joins the right-hand sides of the two substitutions and q_o the second block -- no separate pass
+            const bool isg = lane >= 36;
+            const int a = isg ? (lane - 36) & 7 : (lane >= 28) ? 7 : (lane >= 21) ? 6 : (lane >= 15) ? 5 : (lane >= 10) ? 4 : (lane >= 6) ? 3 : (lane >= 3) ? 2 : (lane >= 1) ? 1 : 0;
+            const int b = isg ? 0 : lane - a * (a + 1) / 2;
+            const double gm = isg ? 1.0 : 0.0;
             double fb[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) fb[c] = S.FG[8 * c + b];
+            for (int c = 0; c < 6; ++c) {
+                const double fgc = S.FG[8 * c + b];
+                fb[c] = isg ? (c < 3 ? -gh[c] : 0.0) : fgc;
+            }
             double w3[3], t3[3], u3[3], yp[3], s2[3], yo[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 w3[i] = dot3(Pa[6 * i + 3], fb[3], Pa[6 * i + 4], fb[4], Pa[6 * i + 5], fb[5]);          // Ppo f_o
-                t3[i] = dot3(Pa[6 * i], fb[0], Pa[6 * i + 1], fb[1], Pa[6 * i + 2], fb[2]) + w3[i];
-                u3[i] = fma(Dv[i], fb[i], -w3[i]);
+                const double qi = gm * ql[i];
+                t3[i] = dot3(Pa[6 * i], fb[0], Pa[6 * i + 1], fb[1], Pa[6 * i + 2], fb[2]) + w3[i] + qi;
+                u3[i] = fma(Dv[i], fb[i], -w3[i]) - qi;
             }
             lu3_solve(lu, t3[0], t3[1], t3[2], yp[0], yp[1], yp[2]);
             lu3_solve(lu, u3[0], u3[1], u3[2], s2[0], s2[1], s2[2]);
@@ -1443,35 +1454,12 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 yo[i] = dot3(Pb[6 * i + 3], fb[3], Pb[6 * i + 4], fb[4], Pb[6 * i + 5], fb[5]) +
-                        dot3(Pb[6 * i], E[0] * s2[0], Pb[6 * i + 1], E[1] * s2[1], Pb[6 * i + 2], E[2] * s2[2]);
-            double v = S.Lall[36 * k + LS(a, b)];
+                        dot3(Pb[6 * i], E[0] * s2[0], Pb[6 * i + 1], E[1] * s2[1], Pb[6 * i + 2], E[2] * s2[2]) + gm * ql[3 + i];
+            double v = isg ? S.lall[8 * k + a] : S.Lall[36 * k + lane];
 #pragma unroll
             for (int c = 0; c < 3; ++c) v = fma(fa[3 + c], yo[c], fma(fa[c], yp[c], v));
-            S.Mall[lane] = v;
-            if (b == 0) {               // gradient: lall + [F G]'(q~ - P~ f), f = (ghat, 0):
-                // (q~ - P~ f)_p = M (q_p - Ppp ghat),  (q~ - P~ f)_o = q_o - Pop E M (q_p + E^-1 ghat)
-                double q[6], r1[3], r2[3], z1[3], z2[3];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) q[i] = ql[i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-#if OBCA_NT == 128          // (256-register build: rows 0-2 are read again from LDS instead of being kept in registers)
-                    r1[i] = q[i] - dot3(Pl[6 * i], gh[0], Pl[6 * i + 1], gh[1], Pl[6 * i + 2], gh[2]);
-#else
-                    r1[i] = q[i] - dot3(Pa[6 * i], gh[0], Pa[6 * i + 1], gh[1], Pa[6 * i + 2], gh[2]);
-#endif
-                    r2[i] = fma(Dv[i], gh[i], q[i]);
-                }
-                lu3_solve(lu, r1[0], r1[1], r1[2], z1[0], z1[1], z1[2]);
-                lu3_solve(lu, r2[0], r2[1], r2[2], z2[0], z2[1], z2[2]);
-                double w = S.lall[8 * k + a];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const double zo = q[3 + i] - dot3(Pb[6 * i], E[0] * z2[0], Pb[6 * i + 1], E[1] * z2[1], Pb[6 * i + 2], E[2] * z2[2]);
-                    w = fma(fa[3 + i], zo, fma(fa[i], z1[i], w));
-                }
-                S.mall[a] = w;
-            }
+            if (lane < 36) S.Mall[lane] = v;
+            else if (lane < 44) S.mall[a] = v;
             // the factors, for the forward pass (nine numbers, like the inverse they replace)
             {
                 const double fsel = lane == 0 ? lu.l10 : lane == 1 ? lu.l20 : lane == 2 ? lu.l21 : lane == 3 ? lu.u01 : lane == 4 ? lu.u02
@@ -1483,18 +1471,18 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
         RPROF(13)
         // ---- phase B ----------------------------------------------------------------------------------
         if (NT == 64 || lane < 64) {
-        const double m00 = S.Mall[8 * 6 + 6], m01 = 0.5 * (S.Mall[8 * 6 + 7] + S.Mall[8 * 7 + 6]), m11 = S.Mall[8 * 7 + 7];
+        const double m00 = S.Mall[LS(6, 6)], m01 = S.Mall[LS(7, 6)], m11 = S.Mall[LS(7, 7)];
         const double d1 = m11 - m01 * m01 / m00;
         if (!(m00 > 0.0) || !(d1 > 0.0)) bad = 1;
         const double idet = 1.0 / (m00 * d1);
         const double i00 = m11 * idet, i01 = -m01 * idet, i11 = m00 * idet;
         if (lane < 42) {
             const int a = (lane < 36) ? lane / 6 : lane - 36, b = (lane < 36) ? lane - 6 * (lane / 6) : 0;
-            const double xa0 = 0.5 * (S.Mall[8 * a + 6] + S.Mall[8 * 6 + a]), xa1 = 0.5 * (S.Mall[8 * a + 7] + S.Mall[8 * 7 + a]);
+            const double xa0 = S.Mall[LS(6, a)], xa1 = S.Mall[LS(7, a)];
             if (lane < 36) {            // P_k = Mxx - Mxu Muu^-1 Mxu'
-                const double xb0 = 0.5 * (S.Mall[8 * b + 6] + S.Mall[8 * 6 + b]), xb1 = 0.5 * (S.Mall[8 * b + 7] + S.Mall[8 * 7 + b]);
+                const double xb0 = S.Mall[LS(6, b)], xb1 = S.Mall[LS(7, b)];
                 const double kb0 = -(i00 * xb0 + i01 * xb1), kb1 = -(i01 * xb0 + i11 * xb1);
-                S.Pk[36 * k + lane] = 0.5 * (S.Mall[8 * a + b] + S.Mall[8 * b + a]) + xa0 * kb0 + xa1 * kb1;
+                S.Pk[36 * k + lane] = S.Mall[LS(a, b)] + xa0 * kb0 + xa1 * kb1;
                 if (a == 0) { S.Kk[12 * k + b] = kb0; S.Kk[12 * k + 6 + b] = kb1; }      // K = -Muu^-1 Mxu'
             } else {
                 const double k0 = -(i00 * S.mall[6] + i01 * S.mall[7]), k1 = -(i01 * S.mall[6] + i11 * S.mall[7]);
