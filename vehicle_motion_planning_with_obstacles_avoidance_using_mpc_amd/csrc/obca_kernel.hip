@@ -1200,11 +1200,19 @@ __device__ __forceinline__ double fg_entry(const Lay& L, const Sh& S, const Inst
 #ifndef OBCA_TWO_SIDED_DMAX
 #define OBCA_TWO_SIDED_DMAX 1.0e6
 #endif
-#ifndef OBCA_SPLIT_NUM      /* the halves meet at stage m = N * NUM / 20: a forward stage (5 x 5 elimination) costs about 1.2 backward stages */
+#ifndef OBCA_SPLIT_NUM      /* the halves meet at stage m = N * NUM / 20: a forward stage (5 x 5 elimination) costs about 1.2-1.4 backward stages; 8, 9 and 10 were timed on C3: 387 / 374 / 380 ms per 8192 free-time solves */
 #define OBCA_SPLIT_NUM 9
 #endif
 #define WSYNC() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
+// reciprocal by v_rcp_f64 and two Newton steps (the forward half rounds in its own way anyway -- nothing is compared with it
+// bit for bit -- so it does not need the correctly rounded quotient's ten dependent instructions; error <= 1 ulp)
+__device__ __forceinline__ double rcp_nr(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+}
 // LDL^T without pivoting of a packed lower triangle (entry (i, j), i >= j, at i (i + 1) / 2 + j), in place: unit factor
 // below the diagonal, reciprocal pivots in id.  Returns 1 on a non-positive pivot.
 template <int n>
@@ -1214,7 +1222,7 @@ __device__ __forceinline__ int ldl_factor(double* s, double* id) {
     for (int j = 0; j < n; ++j) {
         const double d = s[j * (j + 1) / 2 + j];
         bad |= !(d > 0.0);
-        id[j] = 1.0 / d;
+        id[j] = rcp_nr(d);
         double c[n];
 #pragma unroll
         for (int i = j + 1; i < n; ++i) c[i] = s[i * (i + 1) / 2 + j];
