@@ -160,7 +160,8 @@ int obca_set_mode(obca_handle* h, int mode);
  * roundoff (measured in the kernel: 1e-11..1e-10 of the step's size typically); the one-sided sweep rounds exactly like
  * the one-wavefront kernels.  on = -1 (default): two-sided exactly where the one-wavefront kernels cannot run the
  * shape, so that every shape both kernel families can run gives bit-identical results in both; 0: never; 1: always.
- * Environment override at obca_create: OBCA_TWO_SIDED=-1|0|1. */
+ * Environment override at obca_create: OBCA_TWO_SIDED=-1|0|1.  (OBCA_MW8=1: measured experiment, eight wavefronts per
+ * instance for these shapes -- identical iterates, slower; DESIGN.md 4a'.) */
 int obca_set_two_sided_sweep(obca_handle* h, int on);
 
 /* Diagnostic: device buffer [max_batch,20] receiving per-phase shader-clock totals of each instance.

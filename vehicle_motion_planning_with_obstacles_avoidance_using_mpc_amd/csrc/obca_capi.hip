@@ -14,6 +14,8 @@ extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2);
 extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2);
 extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2);          // four wavefronts per instance (obca_kernel_mw.hip)
 extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2);
+extern "C" __global__ void obca_ipm_kernel_mw8_r2(ObcaLaunch A, ObcaLaunch A2);         // eight wavefronts per instance (obca_kernel_mw8.hip, experiment)
+extern "C" __global__ void obca_ipm_kernel_mw8_r3(ObcaLaunch A, ObcaLaunch A2);
 extern "C" __global__ void obca_ipm_kernel_w2_r2(ObcaLaunch A, ObcaLaunch A2);          // two wavefronts per instance (obca_kernel_w2.hip)
 extern "C" __global__ void obca_ipm_kernel_w2_r3(ObcaLaunch A, ObcaLaunch A2);
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
@@ -22,6 +24,7 @@ struct obca_handle {
     obca_dims dims;
     int32_t M, n_max, R_max, inst_off;
     int32_t offm[OBCA_MAX_OBST + 1];
+    bool mw8;                          // OBCA_MW8=1: the four-wavefront shapes run on eight wavefronts (experiment)
     int two_sided;                     // -1: where only the four-wavefront kernels fit (default), 0: never, 1: always
     int64_t lds_bytes, lds_bytes_mw;   // one-wavefront kernels; four-wavefront kernels (+ the two-sided sweep's storage)
     double* prof;
@@ -126,6 +129,14 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     }
     h->mode = 0;
     h->two_sided = -1;
+    h->mw8 = false;
+    if (const char* e = getenv("OBCA_MW8")) {
+        if (atoi(e) == 1 && h->mw_ok && h->R_max <= 1536 && h->lds_bytes_mw + 256 <= 160 * 1024) {
+            const void* fn = h->R_max <= 1024 ? reinterpret_cast<const void*>(obca_ipm_kernel_mw8_r2) : reinterpret_cast<const void*>(obca_ipm_kernel_mw8_r3);
+            if (h->lds_bytes_mw <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_mw) == hipSuccess) h->mw8 = true;
+            else (void)hipGetLastError();
+        }
+    }
     if (const char* e = getenv("OBCA_TWO_SIDED")) { const int v = atoi(e); if (v >= -1 && v <= 1) h->two_sided = v; }
     if (const char* e = getenv("OBCA_MODE")) {
         const int m = atoi(e);                                     // out of range or not available for this shape: auto
@@ -289,7 +300,10 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
         // the kernels run the escalated second solve of a free-time instance themselves, from their own descriptor
         ObcaLaunch L2 = L;
         L2.prm.opt.rho *= OBCA_RHO_ESCALATION;
-        if (mw)
+        if (mw && h->mw8)
+            hipLaunchKernelGGL(h->R_max <= 1024 ? obca_ipm_kernel_mw8_r2 : obca_ipm_kernel_mw8_r3, dim3(B), dim3(512),
+                               (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2);
+        else if (mw)
             hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
                                (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2);
         else if (h->R_max <= 256)

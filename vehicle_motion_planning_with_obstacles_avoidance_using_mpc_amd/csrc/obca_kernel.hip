@@ -1196,7 +1196,7 @@ __device__ __forceinline__ double fg_entry(const Lay& L, const Sh& S, const Inst
 // definite.  Blueprint and its check against the dense solve: oracle/kkt_structured.py (split > 0),
 // tests/test_kkt_structured.py.  Each wavefront only reads what it wrote itself until the halves meet, so the stages
 // are separated by wavefront-level fences (LDS operations of one wavefront complete in order), not workgroup barriers.
-#if OBCA_NT == 256
+#if OBCA_NT >= 256
 #ifndef OBCA_TWO_SIDED_DMAX
 #define OBCA_TWO_SIDED_DMAX 1.0e6
 #endif
@@ -1353,7 +1353,7 @@ __device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, i
 // of the symmetric 8x8 stage matrix Mall = Lall + [F G]' P~ [F G] (36 lanes) or of its gradient (8 lanes, same expression);
 // (B) every lane inverts the 2x2 input block and produces one entry of P_k / q_k / K.  Returns 1 on a wrong-sign pivot; on success dx (poses, inputs, T) and the multiplier steps
 // of the soft rows are written.
-#if OBCA_NT == 256
+#if OBCA_NT >= 256
 // Stage where the two halves of the sweep meet (0: one-sided sweep).  The forward half carries the elastic rows in
 // information form (E^-1 enters its blocks), which loses digits to cancellation once E^-1 is huge (the last few
 // iterations, when the elastic variables vanish: E ~ 1e-10 and below); the backward half's (I + P E)^-1 form does not.
@@ -1384,7 +1384,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
     int bad = 0;
-#if OBCA_NT == 256
+#if OBCA_NT >= 256
 #define RSYNC() WSYNC()
     const int m = allow_two ? two_sided_split(L, S, lane) : 0;
     if (lane < 64) {
@@ -1506,13 +1506,13 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
         }
         RSYNC();
         RPROF(14)
-#if OBCA_NT == 256
+#if OBCA_NT >= 256
         if (__any(bad)) break;
 #else
         if (red_or(bad)) return 1;         // wrong-sign pivot: the attempt is over, no need to finish the sweep
 #endif
     }
-#if OBCA_NT == 256
+#if OBCA_NT >= 256
     } else if (lane < 128 && m > 0) {
         bad |= riccati_forward_half(L, S, in, lane - 64, m);
     }
@@ -1544,7 +1544,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
     }
     double dT = 0.0;
     double dp[3] = {0.0, 0.0, 0.0}, up[2] = {0.0, 0.0};
-#if OBCA_NT == 256
+#if OBCA_NT >= 256
     if (m > 0) {
         // ---- the halves meet: (Pi_m + P_m) xi_m = -(pi_m + q_m), by the first two wavefronts (each for its own half)
         double xi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -2089,7 +2089,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             PROF(4)
 #ifdef OBCA_PROFILE
             if (!bad) bad = riccati(L, S, in, lane, prof_t, A.two_sided != 0);
-#if !defined(OBCA_TWO_SIDED_CHECK) && OBCA_NT == 256
+#if !defined(OBCA_TWO_SIDED_CHECK) && OBCA_NT >= 256
             if (A.two_sided != 0) {         // slots 18 / 19: solves whose sweep ran two-sided / all solves, and the largest E^-1 seen
                 double dmax = 0.0;
                 for (int r = L.r_init + (lane & 63); r < L.r_term; r += 64) dmax = fmax(dmax, S.Einv[r]);
@@ -2099,7 +2099,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 if (dmax <= 4e6 && dmax > 1e6) prof_t[10] += 1;
             }
 #endif
-#if defined(OBCA_TWO_SIDED_CHECK) && OBCA_NT == 256
+#if defined(OBCA_TWO_SIDED_CHECK) && OBCA_NT >= 256
             // dev check: every two-sided solve is repeated one-sided on the same data; slot 18 keeps the largest
             // difference of the steps (poses, inputs, T; relative to the step's largest entry, x 1e18), slot 19 that of
             // the multiplier steps of the elastic rows
@@ -2552,6 +2552,10 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches,
 // two wavefronts per instance, two workgroups' worth of waves per SIMD (register budget capped at 256): rows r = thread + 128 j
 extern "C" __global__ void __launch_bounds__(OBCA_NT, 2) obca_ipm_kernel_w2_r2(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<2>(A, A2); }
 extern "C" __global__ void __launch_bounds__(OBCA_NT, 2) obca_ipm_kernel_w2_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
+#elif OBCA_NT == 512
+// eight wavefronts per instance (two per SIMD, register budget 256): rows r = thread + 512 j, j < 2 (up to 1024 rows) or j < 3 (1536)
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw8_r2(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<2>(A, A2); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw8_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
 #else
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
 extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
