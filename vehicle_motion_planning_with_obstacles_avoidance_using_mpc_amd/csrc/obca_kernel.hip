@@ -1359,8 +1359,8 @@ __device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, i
 // iterations, when the elastic variables vanish: E ~ 1e-10 and below); the backward half's (I + P E)^-1 form does not.
 // Measured on the blueprint (oracle/kkt_structured.py): step error <= 1e-11 relative while E >= 1e-6, up to 1e-8 below;
 // in the kernel itself (-DOBCA_PROFILE -DOBCA_TWO_SIDED_CHECK: every two-sided solve repeated one-sided): see DESIGN.md.
-// So the two-sided sweep serves the iterations with max E^-1 <= OBCA_TWO_SIDED_DMAX -- nine in ten -- and the others
-// run one-sided.  (Every wavefront evaluates the test itself: same data, same result, no barrier.)
+// So the two-sided sweep serves the iterations with max E^-1 <= OBCA_TWO_SIDED_DMAX -- 96 % of the solves of C3's free-time
+// half, 79 % of its gated half -- and the others run one-sided.  (Every wavefront evaluates the test itself: same data, same result, no barrier.)
 __device__ __forceinline__ int two_sided_split(const Lay& L, const Sh& S, int lane) {
     int m = L.N >= 4 ? L.N * OBCA_SPLIT_NUM / 20 : 0;
     if (m > 0) {
