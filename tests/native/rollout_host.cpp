@@ -30,6 +30,7 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
     D.x0 = da(B * 3); D.u0 = da(B * 2); D.Ts = da(B); D.Ts_opt = da(B); D.xprev = da(B * 3 * Nm1); D.dyn = da(B * nd * DYN_W);
     D.k = ia(B); D.flags = ia(B); D.sel = ia(B); D.xref = da(B * 3 * N1); D.xref_fix = da(B * 3 * Nf1); D.term = da(B * 3);
     D.xc = x_closed; D.uc = u_closed; D.Tc = T_closed; D.xol = x_openloop; D.dh = dyn_hist; D.vh = variant_hist; D.ih = iters_hist; D.sh = status_hist;
+    D.vtx = da(B * OBCA_MAX_DYN * 8);
     for (int g = 0; g <= D.n_dyn; ++g) {
         const size_t Mg = D.Ms + 4 * g, N = g == 0 ? D.N : D.Nf, N1 = N + 1;
         D.var[g] = ia(B); D.var8[g] = ia(B); D.A[g] = da(B * N1 * Mg * 2); D.b[g] = da(B * N1 * Mg);

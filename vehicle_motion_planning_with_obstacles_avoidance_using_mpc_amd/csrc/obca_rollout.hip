@@ -121,7 +121,7 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
          dev_alloc(r, D.flags, B) && dev_alloc(r, D.sel, B) && dev_alloc(r, D.xref, B * 3 * N1) && dev_alloc(r, D.xref_fix, B * 3 * Nf1) && dev_alloc(r, D.term, B * 3);
     ok = ok && dev_alloc(r, D.xc, B * (S + 1) * 3) && dev_alloc(r, D.uc, B * S * 2) && dev_alloc(r, D.Tc, B * S) &&
          dev_alloc(r, D.xol, B * S * 3 * Nm1) && dev_alloc(r, D.dh, B * S * nd * 4) && dev_alloc(r, D.vh, B * S) &&
-         dev_alloc(r, D.ih, B * S) && dev_alloc(r, D.sh, B * S);
+         dev_alloc(r, D.ih, B * S) && dev_alloc(r, D.sh, B * S) && dev_alloc(r, D.vtx, B * OBCA_MAX_DYN * 8);
     int rc = ok ? OBCA_OK : OBCA_E_NOMEM;
     for (int g = 0; g <= d->n_dyn && rc == OBCA_OK; ++g) {
         const size_t Mg = D.Ms + 4 * g, Ng = g == 0 ? D.N : D.Nf, Ng1 = Ng + 1;     // group 0: free-time horizon; others: N_fix

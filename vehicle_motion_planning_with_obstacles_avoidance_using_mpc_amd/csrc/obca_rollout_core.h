@@ -52,6 +52,7 @@ struct Dev {
     int32_t *status[MAX_GROUPS], *iters[MAX_GROUPS], *status8[MAX_GROUPS], *iters8[MAX_GROUPS];
     // history (what the reference hands to its plot routine, :435-441)
     double *xc, *uc, *Tc, *xol, *dh;
+    double* vtx;                    // [B, OBCA_MAX_DYN, 4, 2] vertices of the present rectangles of the current step (scratch of prepare())
     int32_t *vh, *ih, *sh;
     // optional warm start (obca_rollouts_set_warm_start): per group the primal vectors kept by the solver and the flags
     // telling it which rollouts may start from them
@@ -119,8 +120,12 @@ RO_FN void prepare(const Dev& D, int b) {
     const double* x0 = D.x0 + 3 * b;
 
     // H2 update_obstacle: appear at k == t_start, afterwards advance by Ts_opt * v along the heading
-    int present[OBCA_MAX_DYN], np = 0;
-    double V[OBCA_MAX_DYN][4][2];
+    // (index lists packed four bits per entry and the vertex lists in a per-rollout HBM row: as local arrays they were 304 B
+    // of stack frame -- scratch -- in the fused closed-loop kernel)
+    static_assert(OBCA_MAX_DYN <= 8, "index lists are packed four bits per entry into one int");
+    unsigned present = 0, sensed = 0;
+    int np = 0;
+    double (*V)[4][2] = reinterpret_cast<double (*)[4][2]>(D.vtx + (size_t)b * OBCA_MAX_DYN * 8);
     for (int i = 0; i < nd; ++i) {
         double* info = D.dyn + ((size_t)b * nd + i) * DYN_W;
         double* rec = D.dh + (((size_t)b * D.S + k) * nd + i) * 4;
@@ -132,11 +137,12 @@ RO_FN void prepare(const Dev& D, int b) {
         }
         rec[0] = info[0]; rec[1] = info[1]; rec[2] = 1.0;
         rect_vertices(info[0], info[1], info[11], info[12], info[3], info[4], V[np]);
-        present[np++] = i;
+        present |= (unsigned)i << (4 * np);
+        ++np;
     }
 
     // H3 sensor: any vertex of a present obstacle within sense_dis of the car-front point
-    int sensed[OBCA_MAX_DYN], ns = 0;
+    int ns = 0;
     {
         const double c = cos(x0[2]), s = sin(x0[2]), l = D.ego_l, w = D.ego_w;
         const double v2x = x0[0] + l * c - w * s, v2y = x0[1] + l * s + w * c;
@@ -146,8 +152,10 @@ RO_FN void prepare(const Dev& D, int b) {
             for (int q = 0; q < 4; ++q) {
                 const double dx = fx - V[j][q][0], dy = fy - V[j][q][1];
                 if (sqrt(dx * dx + dy * dy) <= D.sense_dis) {
-                    sensed[ns++] = present[j];
-                    D.dh[(((size_t)b * D.S + k) * nd + present[j]) * 4 + 3] = 1.0;
+                    const int pj = (int)((present >> (4 * j)) & 15u);
+                    sensed |= (unsigned)pj << (4 * ns);
+                    ++ns;
+                    D.dh[(((size_t)b * D.S + k) * nd + pj) * 4 + 3] = 1.0;
                     break;
                 }
             }
@@ -229,7 +237,7 @@ RO_FN void prepare(const Dev& D, int b) {
         for (int q = 0; q < 2 * D.Ms; ++q) Ak[q] = As[q];
         for (int q = 0; q < D.Ms; ++q) bk[q] = bs[q];
         for (int j = 0; j < ns; ++j) {
-            const double* info = D.dyn + ((size_t)b * nd + sensed[j]) * DYN_W;
+            const double* info = D.dyn + ((size_t)b * nd + (int)((sensed >> (4 * j)) & 15u)) * DYN_W;
             const double sx = Ts_opt * info[5] * info[11] * (double)kk;
             const double sy = Ts_opt * info[5] * info[12] * (double)kk;
             double T[5][2];
