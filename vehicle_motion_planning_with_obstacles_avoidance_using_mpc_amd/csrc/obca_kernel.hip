@@ -2490,7 +2490,8 @@ extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A
 __device__ __noinline__ void ro_prepare(const rollout::Dev* D, int b) { rollout::prepare(*D, b); }
 __device__ __noinline__ void ro_finish(const rollout::Dev* D, int b) { rollout::finish(*D, b); }
 __device__ __noinline__ int ro_retry(const rollout::Dev* D, int g, int b) { rollout::make_retry(*D, g, b); return D->var8[g][b]; }
-__device__ __noinline__ int ro_flag_sel(const rollout::Dev* D, int b, int* sel) { *sel = D->sel[b]; return D->flags[b]; }
+// (flag in the low half, group in the high half: an out-parameter would be a stack slot, i.e. scratch)
+__device__ __noinline__ long long ro_flag_sel(const rollout::Dev* D, int b) { return ((long long)D->sel[b] << 32) | (unsigned)D->flags[b]; }
 
 template <int RPL>
 __device__ __noinline__ void solve_out_of_line(const ObcaLaunch* Lp, int b, int pass) { obca_ipm_body<RPL, true>(*Lp, b, pass); }
@@ -2503,9 +2504,9 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
     for (int step = 0; step < n_steps; ++step) {
         if (lane == 0) {
             ro_prepare(&D, b);
-            int sel;
-            ro_msg[0] = ro_flag_sel(&D, b, &sel);
-            ro_msg[1] = sel;
+            const long long fs = ro_flag_sel(&D, b);
+            ro_msg[0] = (int)(unsigned)fs;
+            ro_msg[1] = (int)(fs >> 32);
         }
         __syncthreads();
         if (ro_msg[0] != OBCA_RUN) break;

@@ -240,11 +240,15 @@ RO_FN void prepare(const Dev& D, int b) {
             const double* info = D.dyn + ((size_t)b * nd + (int)((sensed >> (4 * j)) & 15u)) * DYN_W;
             const double sx = Ts_opt * info[5] * info[11] * (double)kk;
             const double sy = Ts_opt * info[5] * info[12] * (double)kk;
-            double T[5][2];
-            for (int q = 0; q < 4; ++q) { T[q][0] = V[j][q][0] + sx; T[q][1] = V[j][q][1] + sy; }
-            T[4][0] = T[0][0]; T[4][1] = T[0][1];
-            for (int q = 0; q < 4; ++q)
-                edge_row(T[q][0], T[q][1], T[q + 1][0], T[q + 1][1], Ak + 2 * (D.Ms + 4 * j + q), bk + D.Ms + 4 * j + q);
+            // (the four moved vertices as scalars: a local array indexed in a loop is a stack frame)
+            const double x0_ = V[j][0][0] + sx, y0_ = V[j][0][1] + sy, x1_ = V[j][1][0] + sx, y1_ = V[j][1][1] + sy;
+            const double x2_ = V[j][2][0] + sx, y2_ = V[j][2][1] + sy, x3_ = V[j][3][0] + sx, y3_ = V[j][3][1] + sy;
+            double* Ar = Ak + 2 * (D.Ms + 4 * j);
+            double* br = bk + D.Ms + 4 * j;
+            edge_row(x0_, y0_, x1_, y1_, Ar, br);
+            edge_row(x1_, y1_, x2_, y2_, Ar + 2, br + 1);
+            edge_row(x2_, y2_, x3_, y3_, Ar + 4, br + 2);
+            edge_row(x3_, y3_, x0_, y0_, Ar + 6, br + 3);
         }
     }
     D.sel[b] = g;
