@@ -35,6 +35,8 @@ def test_empty_batch_and_argument_errors():
     with pytest.raises(ValueError):
         s.solve(d["variant"], d["x0"][:, :2], d["u0"], d["xref"], d["A"], d["b"], d["Ts"], d["term"])
     assert lib.obca_set_mode(s._h, 7) == -22
+    assert lib.obca_set_two_sided_sweep(s._h, 2) == -22 and lib.obca_set_two_sided_sweep(None, 0) == -22
+    assert lib.obca_set_two_sided_sweep(s._h, -1) == 0
     assert lib.obca_set_warm_start(s._h, p(out.xopt), None, 0.0) == -22         # mu_init must be positive
     s.close()
 
