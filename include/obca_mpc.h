@@ -227,11 +227,16 @@ int obca_rollouts_reset(obca_rollouts* r, const double* start, const double* goa
 int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
 
 /* n_steps iterations for every rollout.  Default (mode 0): when every problem shape fits the wave kernel, ONE launch
- * of a persistent kernel in which each wavefront owns a rollout for all its steps (harness on lane 0, solves on the
- * wave) -- rollouts then advance independently instead of in lock step, so one expensive solve does not hold the batch
- * back; results are identical to n_steps calls of obca_rollouts_step.  Mode 1 forces the lock-step launches. */
+ * of a persistent kernel (harness on lane 0, solves on the wave) whose workgroups -- one per SIMD -- take (round, rollout)
+ * items from a device-side counter: every rollout has done step r before any starts step r + 1, rollouts advance
+ * independently instead of in lock step (one expensive solve does not hold the batch back), and the launch does not end
+ * with a few long rollouts on an otherwise idle GPU.  Results are identical to n_steps calls of obca_rollouts_step.
+ * OBCA_ROLLOUT_QUEUE=0 at obca_rollouts_create: one workgroup per rollout for all its steps (the earlier schedule).
+ * Mode 1 forces the lock-step launches. */
 int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_stream);
 int obca_rollouts_set_mode(obca_rollouts* r, int mode);
+/* Diagnostic (-DOBCA_RO_STATS builds): per persistent workgroup [wait, work (10 ns units), items, end clock], n ints to host */
+int obca_rollouts_debug_stats(obca_rollouts* r, int32_t* out, int n);
 
 /* Optional, NOT reference behaviour (see obca_set_warm_start): a step whose problem shape equals the previous step's
  * starts from the previous plan moved one stage forward with barrier parameter mu_init.  Call before

@@ -39,7 +39,7 @@ class ObcaRolloutDims(ctypes.Structure):
 
 
 EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",
-           "obca_set_profile_buffer", "obca_set_mode", "obca_set_two_sided_sweep", "obca_rollouts_create", "obca_rollouts_destroy",
+           "obca_set_profile_buffer", "obca_set_mode", "obca_set_two_sided_sweep", "obca_rollouts_create", "obca_rollouts_destroy", "obca_rollouts_debug_stats",
            "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read", "obca_rollouts_run",
            "obca_rollouts_set_mode", "obca_astar_batch", "obca_astar_workspace_bytes", "obca_primal_size", "obca_set_warm_start",
            "obca_rollouts_set_warm_start", "obca_dual_size", "obca_set_certificate_buffers", "obca_rasterise_batch")

@@ -2478,7 +2478,7 @@ extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<6>(A, A2); }
 
 // ================================================================== fused closed loop
-// One wavefront owns one rollout for its whole life: lane 0 runs the harness of csrc/obca_rollout_core.h between
+// One wavefront runs one step of one rollout at a time: lane 0 runs the harness of csrc/obca_rollout_core.h around
 // the solves, the wave runs the solves (obca_mpc4, or obca_mpc6 and, where that fails, obca_mpc8).  Nothing is
 // shared between rollouts, so there is no lock step: a rollout that meets an expensive solve (an infeasible
 // obca_mpc6 runs to max_iter before the fallback) does not hold the others back.  `launches[g + a*MAX_GROUPS]`
@@ -2496,12 +2496,60 @@ __device__ __noinline__ long long ro_flag_sel(const rollout::Dev* D, int b) { re
 template <int RPL>
 __device__ __noinline__ void solve_out_of_line(const ObcaLaunch* Lp, int b, int pass) { obca_ipm_body<RPL, true>(*Lp, b, pass); }
 
+// Scheduling.  A rollout used to be one workgroup's job for its whole life (grid = B): with 4096 rollouts of very different
+// cost on 1024 SIMDs the launch ended 36 % after the ideal sum / slots (tools/gpu_tail_c5.py).  Now the unit of work is ONE
+// STEP of one rollout: persistent workgroups (one per SIMD) claim items i = round * B + rollout from a global counter, in
+// order -- so every rollout has done step r before any starts step r + 1.  Measured on C5 (tools/gpu_c5_stats.py): 1.43 -> 1.29 s;
+// the workgroups wait 3 % of their time, and what remains of the tail (0.26 s) is the longest single STEPS (an obca_mpc6 that
+// runs into its iteration limit plus the obca_mpc8 after it: up to 0.3 s) where they happen in the last rounds.  The item's workgroup first waits until the rollout's previous round is published (it was claimed B
+// items earlier: practically always long over); rollout state travels between workgroups through HBM with agent-scope
+// release / acquire (the L2s of the XCDs are not coherent with each other inside a kernel).  Same arithmetic on the same
+// data: results identical to the rollout-per-workgroup schedule (sched == NULL), which the lock-step path reproduces too.
+// sched[0]: next item, sched[1]: abort flag (a wait that never ends must not hang the GPU), sched[2 + b]: rounds done.
+#define OBCA_RO_SPIN_LIMIT (1 << 24)        /* x ~1 us of s_sleep: ~16 s */
+
 template <int RPL>
-__device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* launches, int n_steps) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= D.B) return;
-    __shared__ int ro_msg[2];
-    for (int step = 0; step < n_steps; ++step) {
+__device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* launches, int n_steps, int* sched) {
+    const int lane = threadIdx.x;
+    __shared__ int ro_msg[3];
+    const int total = sched ? n_steps * D.B : n_steps;
+#ifdef OBCA_RO_STATS
+    long long st_wait = 0, st_work = 0, st_t = wall_clock64();
+    int st_items = 0;
+#endif
+    for (int item = 0;; ++item) {
+        int b = blockIdx.x, round = item;
+        if (sched) {
+            if (lane == 0) {
+                int bb = -1, r = 0;
+                const int i = __hip_atomic_fetch_add(&sched[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i < total) {
+                    r = i / D.B;
+                    bb = i - r * D.B;
+                    int spins = 0;
+                    while (__hip_atomic_load(&sched[2 + bb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < r) {
+                        __builtin_amdgcn_s_sleep(32);
+                        if (++spins > OBCA_RO_SPIN_LIMIT || __hip_atomic_load(&sched[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            __hip_atomic_store(&sched[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bb = -1;
+                            break;
+                        }
+                    }
+                }
+                ro_msg[0] = bb;
+                ro_msg[2] = r;
+            }
+            __syncthreads();
+            b = __builtin_amdgcn_readfirstlane(ro_msg[0]);
+            round = __builtin_amdgcn_readfirstlane(ro_msg[2]);
+            __syncthreads();
+#ifdef OBCA_RO_STATS
+            { const long long t = wall_clock64(); st_wait += t - st_t; st_t = t; }
+#endif
+            if (b < 0) break;
+        } else if (item >= total || b >= D.B) {
+            break;
+        }
         if (lane == 0) {
             ro_prepare(&D, b);
             const long long fs = ro_flag_sel(&D, b);
@@ -2509,44 +2557,57 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
             ro_msg[1] = (int)(fs >> 32);
         }
         __syncthreads();
-        if (ro_msg[0] != OBCA_RUN) break;
+        const bool running = ro_msg[0] == OBCA_RUN;
         const int g = __builtin_amdgcn_readfirstlane(ro_msg[1]);     // wave-uniform: the descriptor is read with scalar loads
         __syncthreads();
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            // second attempt: obca_mpc4 -> the escalated pass (rho x 100; returns at once unless the first pass ended
-            // "infeasible"); obca_mpc6 -> obca_mpc8 where obca_mpc6 failed.  One call site: the body is inlined once.
-            const ObcaLaunch* Lp = launches + g;
-            if (attempt == 1) {
-                if (g == 0) Lp = launches + 2 * rollout::MAX_GROUPS;
-                else {
-                    if (lane == 0) ro_msg[0] = ro_retry(&D, g, b);
-                    __syncthreads();
-                    const int v8 = ro_msg[0];
-                    __syncthreads();
-                    if (v8 != 8) break;
-                    Lp = launches + g + rollout::MAX_GROUPS;
+        if (!running && !sched) break;
+        if (running) {
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                // second attempt: obca_mpc4 -> the escalated pass (rho x 100; returns at once unless the first pass ended
+                // "infeasible"); obca_mpc6 -> obca_mpc8 where obca_mpc6 failed.  One call site: the body is inlined once.
+                const ObcaLaunch* Lp = launches + g;
+                if (attempt == 1) {
+                    if (g == 0) Lp = launches + 2 * rollout::MAX_GROUPS;
+                    else {
+                        if (lane == 0) ro_msg[0] = ro_retry(&D, g, b);
+                        __syncthreads();
+                        const int v8 = ro_msg[0];
+                        __syncthreads();
+                        if (v8 != 8) break;
+                        Lp = launches + g + rollout::MAX_GROUPS;
+                    }
                 }
+                obca_ipm_body<RPL, false, ObcaLaunchConst>(*(ObcaLaunchConst*)Lp, b, (attempt == 1 && g == 0) ? 1 : 0);
+                __syncthreads();
             }
-            obca_ipm_body<RPL, false, ObcaLaunchConst>(*(ObcaLaunchConst*)Lp, b, (attempt == 1 && g == 0) ? 1 : 0);
+            if (lane == 0) ro_finish(&D, b);
             __syncthreads();
         }
-        if (lane == 0) ro_finish(&D, b);
-        __syncthreads();
+        if (sched && lane == 0) __hip_atomic_store(&sched[2 + b], round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef OBCA_RO_STATS
+        { const long long t = wall_clock64(); st_work += t - st_t; st_t = t; ++st_items; }
+#endif
     }
+#ifdef OBCA_RO_STATS
+    if (sched && lane == 0) {
+        int* o = sched + 2 + D.B + 4 * blockIdx.x;
+        o[0] = (int)st_wait; o[1] = (int)st_work; o[2] = st_items; o[3] = (int)(wall_clock64() & 0x7fffffff);
+    }
+#endif
 }
 
 // _r4: every shape of the rollout has <= 256 rows (static obstacles only at N=5); _r6: <= 384 rows
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps) {
-    rollout_fused_body<4>(*Dp, launches, n_steps);
+obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched) {
+    rollout_fused_body<4>(*Dp, launches, n_steps, sched);
 }
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps) {
-    rollout_fused_body<5>(*Dp, launches, n_steps);
+obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched) {
+    rollout_fused_body<5>(*Dp, launches, n_steps, sched);
 }
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps) {
-    rollout_fused_body<6>(*Dp, launches, n_steps);
+obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched) {
+    rollout_fused_body<6>(*Dp, launches, n_steps, sched);
 }
 
 #elif OBCA_NT == 128

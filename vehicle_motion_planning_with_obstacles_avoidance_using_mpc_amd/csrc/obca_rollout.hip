@@ -8,9 +8,9 @@
 #include "obca_device.h"
 #include "obca_rollout_core.h"
 
-extern "C" __global__ void obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
-extern "C" __global__ void obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
-extern "C" __global__ void obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps);
+extern "C" __global__ void obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched);
+extern "C" __global__ void obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched);
+extern "C" __global__ void obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched);
 
 namespace {
 
@@ -46,6 +46,9 @@ struct obca_rollouts {
     // fused path: descriptors in HBM for the persistent one-wave-per-rollout kernel (obca_kernel.hip)
     rollout::Dev* dD;
     ObcaLaunch* dL;
+    int32_t* sched;           /* [2 + B] work queue of the fused kernel: next item, abort flag, rounds done per rollout */
+    int n_slots;              /* workgroups the device holds at once (one per SIMD) */
+    int sched_mode;           /* 1: step-granular work queue (default), 0: one workgroup per rollout (OBCA_ROLLOUT_QUEUE=0) */
     ObcaLaunch hL[2 * rollout::MAX_GROUPS + 1];        // [2*MAX_GROUPS] = escalated pass of group 0 (obca_mpc4): rho x 100
     bool fused_ok;
     int32_t rows_max;
@@ -144,6 +147,14 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
     r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0; r->warm_mu = 0.0;
     if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS + 1))) rc = OBCA_E_NOMEM;
+    r->sched = nullptr; r->n_slots = 1024; r->sched_mode = 1;
+    if (rc == OBCA_OK && !dev_alloc(r, r->sched, (size_t)d->batch + 2 + 4 * 4096)) rc = OBCA_E_NOMEM;   // (+ per-workgroup statistics of -DOBCA_RO_STATS builds)
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && cus > 0) r->n_slots = 4 * cus;
+        else (void)hipGetLastError();
+        if (const char* e = getenv("OBCA_ROLLOUT_QUEUE")) r->sched_mode = atoi(e) != 0;
+    }
     if (rc != OBCA_OK) { obca_rollouts_destroy(r); return rc; }
     *out = r;
     return OBCA_OK;
@@ -272,6 +283,11 @@ extern "C" int obca_rollouts_set_warm_start(obca_rollouts* r, int enable, double
     return OBCA_OK;
 }
 
+extern "C" int obca_rollouts_debug_stats(obca_rollouts* r, int32_t* out, int n) {      // -DOBCA_RO_STATS builds: [n_slots][4] ints to host
+    if (!r || !out) return OBCA_E_INVAL;
+    return hipMemcpy(out, r->sched + 2 + r->D.B, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? OBCA_OK : OBCA_E_HIP;
+}
+
 extern "C" int obca_rollouts_set_mode(obca_rollouts* r, int mode) {
     if (!r || mode < 0 || mode > 1) return OBCA_E_INVAL;
     r->mode = mode;
@@ -284,15 +300,20 @@ extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_st
     if (!guard.ok) return OBCA_E_HIP;
     if (n_steps == 0) return OBCA_OK;
     if (r->fused_ok && r->mode == 0) {
+        // persistent workgroups taking (round, rollout) items from a counter; one workgroup per rollout when the queue is off
+        const bool queue = r->sched_mode != 0 && (long long)n_steps * r->D.B < (1ll << 30);
+        int* sched = queue ? r->sched : nullptr;
+        if (queue && hipMemsetAsync(r->sched, 0, sizeof(int32_t) * ((size_t)r->D.B + 2), (hipStream_t)hip_stream) != hipSuccess) return OBCA_E_HIP;
+        const int grid = queue ? (r->D.B < r->n_slots ? r->D.B : r->n_slots) : r->D.B;
         if (r->rows_max <= 256)
-            hipLaunchKernelGGL(obca_rollout_fused_kernel_r4, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
-                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
+            hipLaunchKernelGGL(obca_rollout_fused_kernel_r4, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched);
         else if (r->rows_max <= 320)
-            hipLaunchKernelGGL(obca_rollout_fused_kernel_r5, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
-                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
+            hipLaunchKernelGGL(obca_rollout_fused_kernel_r5, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched);
         else
-            hipLaunchKernelGGL(obca_rollout_fused_kernel_r6, dim3(r->D.B), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
-                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps);
+            hipLaunchKernelGGL(obca_rollout_fused_kernel_r6, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched);
         return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
     }
     for (int i = 0; i < n_steps; ++i) {
