@@ -340,5 +340,11 @@ extern "C" int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_
                     cp(variant_hist, D.vh, sizeof(int32_t) * B * S) && cp(iters_hist, D.ih, sizeof(int32_t) * B * S) && cp(status_hist, D.sh, sizeof(int32_t) * B * S) &&
                     cp(dyn_hist, D.dh, sizeof(double) * B * S * nd * 4) && cp(steps, D.k, sizeof(int32_t) * B) &&
                     cp(flags, D.flags, sizeof(int32_t) * B);
-    return ok ? OBCA_OK : OBCA_E_HIP;
+    if (!ok) return OBCA_E_HIP;
+    // the fused kernel's work queue gives up (instead of hanging the GPU) if a rollout's previous round is never published:
+    // that must not pass for a result
+    int32_t aborted = 0;
+    if (r->sched && (hipMemcpyAsync(&aborted, r->sched + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                     hipStreamSynchronize(s) != hipSuccess)) return OBCA_E_HIP;
+    return aborted ? OBCA_E_HIP : OBCA_OK;
 }
