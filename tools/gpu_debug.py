@@ -1,3 +1,4 @@
+"""dev tool: the nine golden NLP cases (tests/golden/nlp_eval.json) through the drop-in obca() class, next to the numpy oracle"""
 import json, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca

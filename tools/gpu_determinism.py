@@ -1,3 +1,4 @@
+"""dev tool: the four-wavefront kernel run three times on the same batches (several horizons, both C3 halves): bit-identical?"""
 import sys, numpy as np, torch
 sys.path.insert(0,'.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc

@@ -1,3 +1,5 @@
+"""dev tool: the closed loop of 64 C5 worlds run fused, lock-step, and lock-step on the four-wavefront kernel (OBCA_MODE=3):
+which outputs differ, and on which rollouts"""
 import sys, os, numpy as np, torch
 sys.path.insert(0,'.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds

@@ -1,3 +1,5 @@
+"""dev tool: per-phase shader-clock shares of the solver (library built by tools/build_prof.sh with -DOBCA_PROFILE):
+python tools/gpu_prof.py B c2|c3|c3free N"""
 import sys, ctypes, numpy as np, torch
 sys.path.insert(0, '.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import _lib, scenarios as sc

@@ -1,3 +1,5 @@
+"""dev tool: C3 gated half at B = 2048, one-sided against two-sided sweep: launch time, and the instances with the most
+iterations (the ones that run into the 1000-iteration limit decide the launch time at this batch size)"""
 import sys, time, numpy as np, torch
 sys.path.insert(0,'.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc

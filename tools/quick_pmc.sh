@@ -1,3 +1,4 @@
+# dev tool: FETCH_SIZE / WRITE_SIZE of the headline kernel, one --pmc pass each (kernel trace only)
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/quick; rm -rf $OUT; mkdir -p $OUT
 python tools/gpu_soc_check.py c2 512 2>&1 | tail -3

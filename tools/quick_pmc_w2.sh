@@ -1,3 +1,4 @@
+# dev tool: the PMC passes of tools/quick_pmc.sh for the two-wavefront kernel (mode 4)
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_r02/pmc_c2w2_SQ; rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT -o r02 -- python tools/gpu_profile_targets.py c2w2 3 > $OUT.log 2>&1
