@@ -2527,7 +2527,8 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
                     r = i / D.B;
                     bb = i - r * D.B;
                     int spins = 0;
-                    while (__hip_atomic_load(&sched[2 + bb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < r) {
+                    // (poll relaxed -- an acquire load in the loop would invalidate this CU's L1 on every turn -- and acquire ONCE below)
+                    while (__hip_atomic_load(&sched[2 + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r) {
                         __builtin_amdgcn_s_sleep(32);
                         if (++spins > OBCA_RO_SPIN_LIMIT || __hip_atomic_load(&sched[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                             __hip_atomic_store(&sched[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2536,6 +2537,9 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
                         }
                     }
                 }
+                // the rollout's state was written by another workgroup, possibly on another XCD: agent-scope acquire on THIS CU
+                // (drops its L1 lines) before anything of it is read -- also when no waiting was needed
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 ro_msg[0] = bb;
                 ro_msg[2] = r;
             }
@@ -2583,7 +2587,18 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
             if (lane == 0) ro_finish(&D, b);
             __syncthreads();
         }
-        if (sched && lane == 0) __hip_atomic_store(&sched[2 + b], round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (sched) {
+            // publish: every store of this wave drained, then ONE agent-scope release (writes back the XCD's L2), then the flag.
+            // The explicit wait after the fence restates the one the compiler (ROCm 7.2) drops when it believes the wave has
+            // nothing outstanding -- the flag must not overtake the write-back (MI355X guide, inter-workgroup visibility).
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (lane == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&sched[2 + b], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
 #ifdef OBCA_RO_STATS
         { const long long t = wall_clock64(); st_work += t - st_t; st_t = t; ++st_items; }
 #endif
