@@ -2507,12 +2507,17 @@ __device__ __noinline__ void solve_out_of_line(const ObcaLaunch* Lp, int b, int 
 // data: results identical to the rollout-per-workgroup schedule (sched == NULL), which the lock-step path reproduces too.
 // sched[0]: next item, sched[1]: abort flag (a wait that never ends must not hang the GPU), sched[2 + b]: rounds done.
 #define OBCA_RO_SPIN_LIMIT (1 << 24)        /* x ~1 us of s_sleep: ~16 s */
+#ifndef OBCA_RO_BLOCK                       /* consecutive steps of a rollout per item: 1, 2, 3 run the C5 batch in the same 1.28-1.29 s; */
+#define OBCA_RO_BLOCK 3                     /* 3 means a third of the hand-offs (each release writes back its XCD's dirty L2 lines)       */
+#endif
 
 template <int RPL>
 __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* launches, int n_steps, int* sched) {
     const int lane = threadIdx.x;
     __shared__ int ro_msg[3];
-    const int total = sched ? n_steps * D.B : n_steps;
+    // (an item may cover OBCA_RO_BLOCK consecutive steps of its rollout: fewer hand-offs, coarser schedule)
+    const int KB = sched ? OBCA_RO_BLOCK : 1;
+    const int total = sched ? ((n_steps + KB - 1) / KB) * D.B : n_steps;
 #ifdef OBCA_RO_STATS
     long long st_wait = 0, st_work = 0, st_t = wall_clock64();
     int st_items = 0;
@@ -2554,6 +2559,9 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
         } else if (item >= total || b >= D.B) {
             break;
         }
+        bool running = true;
+        for (int sub = 0; sub < KB && running; ++sub) {
+        if (sched && round * KB + sub >= n_steps) break;
         if (lane == 0) {
             ro_prepare(&D, b);
             const long long fs = ro_flag_sel(&D, b);
@@ -2561,10 +2569,9 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
             ro_msg[1] = (int)(fs >> 32);
         }
         __syncthreads();
-        const bool running = ro_msg[0] == OBCA_RUN;
+        running = ro_msg[0] == OBCA_RUN;
         const int g = __builtin_amdgcn_readfirstlane(ro_msg[1]);     // wave-uniform: the descriptor is read with scalar loads
         __syncthreads();
-        if (!running && !sched) break;
         if (running) {
             for (int attempt = 0; attempt < 2; ++attempt) {
                 // second attempt: obca_mpc4 -> the escalated pass (rho x 100; returns at once unless the first pass ended
@@ -2587,6 +2594,8 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
             if (lane == 0) ro_finish(&D, b);
             __syncthreads();
         }
+        }
+        if (!running && !sched) break;
         if (sched) {
             // publish: every store of this wave drained, then ONE agent-scope release (writes back the XCD's L2), then the flag.
             // The explicit wait after the fence restates the one the compiler (ROCm 7.2) drops when it believes the wave has
