@@ -228,7 +228,8 @@ int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
 
 /* n_steps iterations for every rollout.  Default (mode 0): when every problem shape fits the wave kernel, ONE launch
  * of a persistent kernel (harness on lane 0, solves on the wave) whose workgroups -- one per SIMD -- take (round, rollout)
- * items from a device-side counter: every rollout has done step r before any starts step r + 1, rollouts advance
+ * items (a round = three consecutive steps) from a device-side counter: every rollout has done round r before any starts
+ * round r + 1, rollouts advance
  * independently instead of in lock step (one expensive solve does not hold the batch back), and the launch does not end
  * with a few long rollouts on an otherwise idle GPU.  Results are identical to n_steps calls of obca_rollouts_step.
  * OBCA_ROLLOUT_QUEUE=0 at obca_rollouts_create: one workgroup per rollout for all its steps (the earlier schedule).

@@ -2498,8 +2498,8 @@ __device__ __noinline__ void solve_out_of_line(const ObcaLaunch* Lp, int b, int 
 
 // Scheduling.  A rollout used to be one workgroup's job for its whole life (grid = B): with 4096 rollouts of very different
 // cost on 1024 SIMDs the launch ended 36 % after the ideal sum / slots (tools/gpu_tail_c5.py).  Now the unit of work is ONE
-// STEP of one rollout: persistent workgroups (one per SIMD) claim items i = round * B + rollout from a global counter, in
-// order -- so every rollout has done step r before any starts step r + 1.  Measured on C5 (tools/gpu_c5_stats.py): 1.43 -> 1.29 s;
+// ROUND (OBCA_RO_BLOCK consecutive steps) of one rollout: persistent workgroups (one per SIMD) claim items i = round * B +
+// rollout from a global counter, in order -- so every rollout has done round r before any starts round r + 1.  Measured on C5 (tools/gpu_c5_stats.py): 1.43 -> 1.29 s;
 // the workgroups wait 3 % of their time, and what remains of the tail (0.26 s) is the longest single STEPS (an obca_mpc6 that
 // runs into its iteration limit plus the obca_mpc8 after it: up to 0.3 s) where they happen in the last rounds.  The item's workgroup first waits until the rollout's previous round is published (it was claimed B
 // items earlier: practically always long over); rollout state travels between workgroups through HBM with agent-scope
