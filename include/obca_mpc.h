@@ -58,6 +58,10 @@ typedef struct obca_params {
     double rho;                        /* [1e4]   elastic (l1) penalty, unscaled objective units; a free-time solve
                                                    that ends with elastic variables left is repeated once with
                                                    rho x 100 (exact-penalty escalation)                      */
+    /* Recovery (not an option): a solve that ends without a feasible point -- status 2, -1, -2, -3 -- is repeated once from
+       the reference window xref (poses = xref, first pose x0; inputs by differences) instead of the reference's all-zero
+       start, inside the same launch ("restart phase"; rule and measurements: oracle/ipm_dense.py:solve).  The status,
+       iteration and factorisation counts returned are those of the whole sequence. */
     double feas_tol;                   /* [1e-6]  largest elastic variable still called feasible   */
     int32_t max_iter_free;             /* [3000]  IPOPT default, variant 4                         */
     int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8                       */
@@ -149,9 +153,7 @@ int obca_set_certificate_buffers(obca_handle* h, double* z, double* y);
  * working set still fits the LDS (<= 768 rows, e.g. N = 20 with three obstacles); else the lane-per-instance kernel.
  * 1 = one wavefront per instance; 2 = lane-per-instance (64 instances per wavefront, working set in an HBM workspace
  * owned by the handle; any shape, e.g. N = 20 with five obstacles); 3 = four wavefronts per instance.
- * 4 = two wavefronts per instance with a 256-register budget, i.e. two waves per SIMD (experimental; shapes with <= 384 rows
- * and <= 64 KB of LDS; bit-identical to mode 1, measured 5 % slower on the headline workload -- DESIGN.md section 4a).
- * Returns OBCA_E_LDS if mode 1 / 3 / 4 cannot hold the shape. */
+ * Returns OBCA_E_LDS if mode 1 / 3 cannot hold the shape. */
 int obca_set_mode(obca_handle* h, int mode);
 
 /* Four-wavefront kernels (OBCA_MODE 3, and auto mode for shapes whose rows do not fit one wavefront's registers): the

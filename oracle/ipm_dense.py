@@ -39,6 +39,8 @@ and the independent known answers of SURVEY.md Appendix C
 This dense version is the readable specification; oracle/obca_oracle.c is the
 same algorithm in C (the CPU baseline); the HIP kernel is checked against both.
 """
+import math
+
 import numpy as np
 import scipy.linalg
 
@@ -118,31 +120,74 @@ def split_rows(p):
 
 
 RHO_ESCALATION = 100.0
+RESTART_MU = 1.0               # barrier parameter a restart begins with (csrc/obca_device.h: OBCA_RESTART_MU)
+WINDOW_SPEED_FRAC = 0.9
+
+
+def window_start(p):
+    """Start point of the restart phase: the poses of the reference window the call was given (first pose = x0), the
+    inputs that drive from pose to pose (finite differences, clipped to the input box), for the free-time problem the
+    time scale at which the window is driven at 0.9 of the speed bound (at least 1, at most max_Topt); lambda = mu = 0."""
+    z = np.zeros(p.n)
+    pts = p.xref.copy()
+    pts[:, 0] = p.x0
+    T = 1.0
+    if p.variant == 4:
+        length = 0.0
+        for k in range(p.N):
+            length += math.sqrt((pts[0, k + 1] - pts[0, k]) ** 2 + (pts[1, k + 1] - pts[1, k]) ** 2)
+        T = min(max(1.0, length / (p.N * WINDOW_SPEED_FRAC * p.uU[0] * p.Ts)), max(1.0, p.Tmax))
+        z[p.iT()] = T
+    h = p.Ts * T
+    for k in range(p.N + 1):
+        z[p.ip(k):p.ip(k) + 3] = pts[:, k]
+        if k < p.N:
+            d = pts[:, k + 1] - pts[:, k]
+            z[p.iu(k)] = min(max(math.sqrt(d[0] * d[0] + d[1] * d[1]) / h, p.uL[0]), p.uU[0])
+            z[p.iu(k) + 1] = min(max(d[2] / h, p.uL[1]), p.uU[1])
+    return z
 
 
 def solve(p, opts=None, trace=None):
-    """The elastic IPM with ONE penalty escalation for the free-time problem: the l1 penalty is exact only while rho
-    exceeds the multipliers; if obca_mpc4 converges with elastic variables left (which is what "infeasible" looks
-    like, but also what a too small rho looks like -- seen on the open-loop problem of demo1, N = 10) the solve is
-    repeated from the cold start with rho * 100.  A genuinely infeasible problem stays infeasible.  The fixed-time
-    variants are not escalated: the reference has its own obca_mpc6 -> obca_mpc8 fallback for them."""
+    """The elastic IPM from the reference's cold start, followed where needed by two recovery passes (same rule in
+    oracle/obca_oracle.c, csrc/obca_lpi_core.h and the wave kernels):
+
+    * penalty escalation (free-time problem only): the l1 penalty is exact only while rho exceeds the multipliers; if
+      obca_mpc4 converges with elastic variables left (what "infeasible" looks like, but also what a too small rho looks
+      like -- seen on the open-loop problem of demo1, N = 10) the solve is repeated from the cold start with rho * 100;
+    * restart phase (every variant): a solve that still has not converged to a feasible point -- infeasible stationary
+      point of the penalty problem, line-search failure, iteration limit, numerical failure -- is repeated from
+      ``window_start``.  IPOPT answers such endings with its feasibility-restoration phase; measured on the failing
+      instances (tools/restoration_study.py) the restoration problem min ||c||_1 + zeta/2 ||D(x - x_R)||^2 started AT the
+      stationary point x_R does not move (the l1 merit is at a local minimum there: a plan that dives under / through a
+      moving box), whereas the same method started from the reference window -- the only other point the call's own
+      inputs describe -- with a ten times larger barrier parameter (IPOPT raises mu to max(mu, ||c||_inf) when it enters
+      restoration) converges on 97 % of them.  A genuinely infeasible problem stays infeasible."""
+    opts = dict(opts or {})
     r = _solve_once(p, opts, trace)
-    if r.status == STATUS_INFEASIBLE and p.variant == 4 and not (opts or {}).get("no_escalation"):
-        o2 = dict(opts or {})
-        o2["rho"] = (opts or {}).get("rho", DEFAULTS["rho"]) * RHO_ESCALATION
-        r2 = _solve_once(p, o2, trace)
-        r2.iters += r.iters
-        r2.nfact = getattr(r2, "nfact", 0) + getattr(r, "nfact", 0)
-        return r2
+    rho0 = opts.get("rho", DEFAULTS["rho"])
+    if r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation"):
+        r = _accumulate(_solve_once(p, dict(opts, rho=rho0 * RHO_ESCALATION), trace), r)
+    if r.status not in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS) and not opts.get("no_restart"):
+        esc = p.variant == 4 and r.status == STATUS_INFEASIBLE and not opts.get("no_escalation")
+        o3 = dict(opts, rho=rho0 * (RHO_ESCALATION if esc else 1.0), mu_init=RESTART_MU)
+        r = _accumulate(_solve_once(p, o3, trace, x_start=window_start(p)), r)
+        r.restarted = True
     return r
 
 
-def _solve_once(p, opts=None, trace=None):
+def _accumulate(r_new, r_old):
+    r_new.iters += r_old.iters
+    r_new.nfact = getattr(r_new, "nfact", 0) + getattr(r_old, "nfact", 0)
+    return r_new
+
+
+def _solve_once(p, opts=None, trace=None, x_start=None):
     o = options_for(p.variant)
     if opts:
         o.update(opts)
     n = p.n
-    x = p.start_point()
+    x = p.start_point() if x_start is None else np.array(x_start, float)
     hard, term = split_rows(p)
     lbI, ubI = p.ineq_bounds()
     nt = term.size
@@ -242,9 +287,6 @@ def _solve_once(p, opts=None, trace=None):
         return max(dual / sd, prim, comp / sc), dual, prim, comp
 
     filt = []
-    npair = (p.N + 1) * p.nObs
-    R_max = 3 + 3 * p.N + 3 + 2 * (p.N + 1) + 4 * p.N + 2 + 2 * npair + (p.N + 1) * (p.M + 4 * p.nObs)
-    filt_cap = 64 if R_max <= 384 else 128
     th0 = theta_of(ch, ge, s, ep, en)
     theta_max = o["theta_max_fact"] * max(1.0, th0)
     theta_min = o["theta_min_fact"] * max(1.0, th0)
@@ -478,10 +520,7 @@ def _solve_once(p, opts=None, trace=None):
         if aug:
             tn, pn_ = (1 - o["gamma_theta"]) * th, phi - o["gamma_phi"] * th
             filt = [(tf, pf) for (tf, pf) in filt if not (tf >= tn and pf >= pn_)]   # drop dominated entries
-            if len(filt) >= filt_cap:            # capacity rule of the kernels (csrc/obca_device.h: OBCA_FILTER_CAP)
-                status = STATUS_NUMERIC
-                break
-            filt.append((tn, pn_))
+            filt.append((tn, pn_))               # unbounded, as IPOPT's (the kernels hold 64 / 128 entries: OBCA_FILTER_CAP)
             res.max_filter = max(getattr(res, "max_filter", 0), len(filt))
         a_used = step[0]
         f_prev = fobj

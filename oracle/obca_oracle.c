@@ -355,6 +355,8 @@ typedef struct {
 } Opts;
 
 #define MU_INIT 0.1
+#define RESTART_MU 1.0            /* csrc/obca_device.h: OBCA_RESTART_MU */
+#define WINDOW_SPEED_FRAC 0.9
 #define KAPPA_MU 0.2
 #define THETA_MU 1.5
 #define KAPPA_EPS 10.0
@@ -376,13 +378,13 @@ typedef struct {
 #define KW_PLUS 8.0
 #define KW_PLUS_BAR 100.0
 #define KW_MINUS (1.0 / 3.0)
-#define MAXFILT 256
 
 typedef struct { double *s, *p, *n, *y, *zL, *zU, *zp, *zn, *lb, *ub, *w; int* eq; } Rows;
 
 static double maxabs(const double* v, int n) { double m = 0; for (int i = 0; i < n; ++i) m = fmax(m, fabs(v[i])); return m; }
 
-static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double* ts, int* iters, double* info) {
+/* from_window: restart phase -- start from the reference window (oracle/ipm_dense.py:window_start) with barrier parameter mu0 */
+static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double* ts, int* iters, double* info, int from_window, double mu0) {
     const int n = p->n, mh = p->mh, me = p->me, na = p->naug, N = p->N;
     const int nk = n + mh + na;
     /* T rows carry multiplicity N+1 in the dense layout by being repeated (like oracle/obca_nlp.py) */
@@ -404,20 +406,40 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
     double *yh = TAKE(mh), *dyh = TAKE(mh), *ch = TAKE(mh), *cht = TAKE(mh);
     double *Je = TAKE((size_t)me * n), *Jh = TAKE((size_t)mh * n), *W = TAKE((size_t)n * n), *K = TAKE((size_t)nk * nk), *rhs = TAKE(nk), *sol = TAKE(nk);
     (void)gt_; (void)tmpn;
-    double filt_t[MAXFILT], filt_p[MAXFILT];
+    /* the line-search filter is unbounded, as IPOPT's (the kernels hold 64 / 128 entries: csrc/obca_device.h OBCA_FILTER_CAP) */
+    int filt_room = 256;
+    double* filt_t = (double*)malloc(sizeof(double) * 2 * filt_room);
+    double* filt_p = filt_t + filt_room;
     int nfilt = 0, status = ST_MAXITER, it = 0, nfact = 0;
-    const int np_ = (N + 1) * p->nO;
-    const int R_max = 3 + 3 * N + 3 + 2 * (N + 1) + 2 * N + 2 * N + 2 + 2 * np_ + (N + 1) * p->M + (N + 1) * 4 * p->nO;
-    const int filt_cap = R_max <= 384 ? 64 : 128;
+    if (!filt_t) { free(mem); free(piv); free(eq); return ST_NUMERIC; }
     for (int i = 0; i < n; ++i) x[i] = 0;
     if (p->freeT) x[iT(p)] = 1.0;
+    if (from_window) {
+        const int N1 = N + 1;
+        for (int k = 0; k <= N; ++k) for (int j = 0; j < 3; ++j) x[ip(p, k) + j] = k == 0 ? p->x0[j] : p->xref[j * N1 + k];
+        if (p->freeT) {
+            double len = 0.0;
+            for (int k = 0; k < N; ++k) {
+                const double ddx = x[ip(p, k + 1)] - x[ip(p, k)], ddy = x[ip(p, k + 1) + 1] - x[ip(p, k) + 1];
+                len += sqrt(ddx * ddx + ddy * ddy);
+            }
+            x[iT(p)] = fmin(fmax(1.0, len / (N * WINDOW_SPEED_FRAC * p->uU[0] * p->Ts)), fmax(1.0, p->Tmax));
+        }
+        const double h = p->Ts * (p->freeT ? x[iT(p)] : 1.0);
+        for (int k = 0; k < N; ++k) {
+            const double ddx = x[ip(p, k + 1)] - x[ip(p, k)], ddy = x[ip(p, k + 1) + 1] - x[ip(p, k) + 1];
+            const double dth = x[ip(p, k + 1) + 2] - x[ip(p, k) + 2];
+            x[iu(p, k)] = fmin(fmax(sqrt(ddx * ddx + ddy * ddy) / h, p->uL[0]), p->uU[0]);
+            x[iu(p, k) + 1] = fmin(fmax(dth / h, p->uL[1]), p->uU[1]);
+        }
+    }
     /* scaling */
     objective(p, x, g, NULL);
     double gmax = fmax(maxabs(g, n), o->rho);
     const double sf = gmax > 100.0 ? 100.0 / gmax : 1.0, rho = o->rho * sf;
     elastic_rows(p, x, ge, lb, ub, NULL, NULL, NULL);
     int bad_bounds = 0;
-    double mu = MU_INIT;
+    double mu = mu0;
     for (int r = 0; r < me; ++r) {
         eq[r] = r < na;
         const int hasL = !eq[r] && lb[r] > -INF, hasU = !eq[r] && ub[r] < INF;
@@ -717,7 +739,13 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
                 int w = 0;
                 for (int i = 0; i < nfilt; ++i) if (!(filt_t[i] >= tn && filt_p[i] >= pn)) { filt_t[w] = filt_t[i]; filt_p[w] = filt_p[i]; ++w; }
                 nfilt = w;
-                if (nfilt >= filt_cap) { status = ST_NUMERIC; break; }   /* same capacity rule as the kernels (csrc/obca_device.h) */
+                if (nfilt >= filt_room) {
+                    double* nf = (double*)malloc(sizeof(double) * 4 * filt_room);
+                    if (!nf) { status = ST_NUMERIC; break; }
+                    memcpy(nf, filt_t, sizeof(double) * nfilt); memcpy(nf + 2 * filt_room, filt_p, sizeof(double) * nfilt);
+                    free(filt_t);
+                    filt_t = nf; filt_p = nf + 2 * filt_room; filt_room *= 2;
+                }
                 filt_t[nfilt] = tn; filt_p[nfilt] = pn; ++nfilt;
             }
             for (int r = 0; r < me; ++r) {
@@ -748,7 +776,7 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
     *iters = it;
     if (info) { info[0] = objective(p, x, NULL, NULL); info[1] = elastic; info[2] = E0; info[3] = nfact; }
     (void)bx;
-    free(mem); free(piv); free(eq);
+    free(mem); free(piv); free(eq); free(filt_t);
     return status;
 }
 
@@ -810,14 +838,24 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         o.tol = prm->tol > 0 ? prm->tol : 1e-8; o.rho = prm->rho > 0 ? prm->rho : 1e4; o.feas_tol = prm->feas_tol > 0 ? prm->feas_tol : 1e-6;
         o.max_iter_free = prm->max_iter_free > 0 ? prm->max_iter_free : 3000; o.max_iter_fixed = prm->max_iter_fixed > 0 ? prm->max_iter_fixed : 1000;
         o.max_soc = prm->max_soc == 0 ? 4 : (prm->max_soc < 0 ? 0 : prm->max_soc);
-        status[q] = solve_one(&p, &o, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL);
+        status[q] = solve_one(&p, &o, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, 0, MU_INIT);
         if (status[q] == ST_INFEASIBLE && p.variant == 4) {
             /* one penalty escalation for the free-time problem (see oracle/ipm_dense.py:solve): cold start again, rho x 100 */
             Opts o2 = o;
             o2.rho = o.rho * 100.0;
             const int it1 = iters[q];
             const double nf1 = info ? info[(size_t)q * 4 + 3] : 0.0;
-            status[q] = solve_one(&p, &o2, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL);
+            status[q] = solve_one(&p, &o2, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, 0, MU_INIT);
+            iters[q] += it1;
+            if (info) info[(size_t)q * 4 + 3] += nf1;
+        }
+        if (!(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
+            /* restart phase (oracle/ipm_dense.py:solve): once more from the reference window, mu = RESTART_MU */
+            Opts o3 = o;
+            if (p.variant == 4 && status[q] == ST_INFEASIBLE) o3.rho = o.rho * 100.0;
+            const int it1 = iters[q];
+            const double nf1 = info ? info[(size_t)q * 4 + 3] : 0.0;
+            status[q] = solve_one(&p, &o3, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, 1, RESTART_MU);
             iters[q] += it1;
             if (info) info[(size_t)q * 4 + 3] += nf1;
         }

@@ -189,41 +189,3 @@ def test_invalid_variants_are_per_instance_errors():
         assert rc == 0 and outs[3].cpu().tolist() == [_lib.STATUS_BAD_VARIANT, 0, _lib.STATUS_SKIPPED, 0]
         assert float(outs[0][0].abs().max()) == 0.0
         s.close()
-
-
-def test_two_wavefront_kernel_is_bit_identical():
-    """mode 4 ("twowave", experimental): two wavefronts per instance at two waves per SIMD (256 registers per lane), local
-    blocks in the cooperative four-lanes-per-pair form (quad broadcasts).  Every entry goes through the same operations in
-    the same order as in the one-wavefront kernel: identical iterates, bit for bit."""
-    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
-    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
-    for b, N in ((sc.make_batch(256, 5), 5), (sc.make_batch(32, 5, three_boxes=True), 5), (sc.make_batch_c3(16, 5, gated=True), 5)):
-        res = []
-        for mode in ("wave", "twowave"):
-            s = BatchSolver(N, b["m"], max_batch=len(b["variant"]), mode=mode)
-            o = s.solve(b["variant"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], SolverParams())
-            torch.cuda.synchronize()
-            res.append((o.xopt.cpu().numpy(), o.uopt.cpu().numpy(), o.status.cpu().numpy(), o.iters.cpu().numpy()))
-            s.close()
-        for a, c in zip(*res):
-            assert np.array_equal(a, c)
-
-
-def test_eight_wavefront_experiment_is_bit_identical(monkeypatch):
-    """OBCA_MW8=1 (experiment, DESIGN.md 4a'): the four-wavefront shapes on eight wavefronts per instance (two per SIMD,
-    256 registers per lane, two or three rows per thread).  Slower (the factorisation phases spill), but the same code on
-    the same data: identical iterates with the same (two-sided) sweep."""
-    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
-    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
-    for gated in (False, True):
-        b = sc.make_batch_c3(24, 20, gated=gated)
-        res = []
-        for env in ("0", "1"):
-            monkeypatch.setenv("OBCA_MW8", env)
-            s = BatchSolver(20, b["m"], max_batch=24)
-            o = s.solve(b["variant"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], SolverParams())
-            torch.cuda.synchronize()
-            res.append((o.xopt.cpu().numpy(), o.status.cpu().numpy(), o.iters.cpu().numpy()))
-            s.close()
-        for a, c in zip(*res):
-            assert np.array_equal(a, c)

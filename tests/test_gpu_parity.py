@@ -79,23 +79,30 @@ def test_infeasible_instance_reports_feas_false(nlp_golden, solver_cls):
 
 @pytest.mark.parametrize("name", ["demo1_dyn_mpc6", "demo1_dyn_mpc8"])
 def test_hard_fixed_time_cases_are_certified(nlp_golden, solver_cls, name):
-    """long non-convex runs: kernel and oracle may settle in different local optima; each must be a KKT point"""
+    """long non-convex runs.  demo1_dyn_mpc6 is SURVEY Appendix C's "mpc6 witness": from the reference's cold start the
+    method ends at an infeasible stationary point (the plan that dives under the moving box), the restart phase finds the
+    plan that passes above it -- the survey's criterion is feas = True with f <= 0.02974."""
     case = [c for c in nlp_golden if c["name"] == name][0]
     p = build(case)
     x, u, feas, ts = getattr(solver_cls(), "obca_mpc%d" % case["variant"])(*ref_args(case))
     r = ipm_dense.solve(p)
-    assert feas == r.feas
-    if feas:
-        # primal feasibility of the kernel's trajectory in the ORIGINAL NLP (dynamics + bounds on x,u)
-        z = p.start_point()
-        for k in range(p.N + 1):
-            z[p.ip(k):p.ip(k) + 3] = x[:, k]
-            if k < p.N:
-                z[p.iu(k):p.iu(k) + 2] = u[:, k]
-        c = p.eq(z)
-        lay = p.eq_layout()
-        dyn = np.array([abs(c[i]) for i, row in enumerate(lay) if row[0] in ("init", "dyn")])
-        assert dyn.max() < 1e-7
+    assert feas and r.feas
+    np.testing.assert_allclose(x, r.xopt, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(u, r.uopt, rtol=0, atol=1e-5)
+    if name == "demo1_dyn_mpc6":
+        assert getattr(r, "restarted", False)
+        assert r.f <= 0.02974 + 1e-6                                     # SURVEY Appendix C
+    # primal feasibility of the kernel's trajectory in the ORIGINAL NLP (dynamics + bounds on x,u)
+    z = p.start_point()
+    for k in range(p.N + 1):
+        z[p.ip(k):p.ip(k) + 3] = x[:, k]
+        if k < p.N:
+            z[p.iu(k):p.iu(k) + 2] = u[:, k]
+    c = p.eq(z)
+    lay = p.eq_layout()
+    dyn = np.array([abs(c[i]) for i, row in enumerate(lay) if row[0] in ("init", "dyn")])
+    assert dyn.max() < 1e-7
+    assert p.objective(z) == pytest.approx(r.f, abs=1e-7)
 
 
 def test_batch_matches_oracle_and_is_permutation_invariant():

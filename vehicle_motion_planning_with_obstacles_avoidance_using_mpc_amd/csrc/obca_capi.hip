@@ -9,22 +9,17 @@
 #include "obca_device.h"
 #include "obca_lpi_core.h"
 
-extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2);
-extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2);
-extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2);
-extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2);          // four wavefronts per instance (obca_kernel_mw.hip)
-extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2);
-extern "C" __global__ void obca_ipm_kernel_mw8_r2(ObcaLaunch A, ObcaLaunch A2);         // eight wavefronts per instance (obca_kernel_mw8.hip, experiment)
-extern "C" __global__ void obca_ipm_kernel_mw8_r3(ObcaLaunch A, ObcaLaunch A2);
-extern "C" __global__ void obca_ipm_kernel_w2_r2(ObcaLaunch A, ObcaLaunch A2);          // two wavefronts per instance (obca_kernel_w2.hip)
-extern "C" __global__ void obca_ipm_kernel_w2_r3(ObcaLaunch A, ObcaLaunch A2);
+extern "C" __global__ void obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
+extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
+extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
+extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);          // four wavefronts per instance (obca_kernel_mw.hip)
+extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
 struct obca_handle {
     obca_dims dims;
     int32_t M, n_max, R_max, inst_off;
     int32_t offm[OBCA_MAX_OBST + 1];
-    bool mw8;                          // OBCA_MW8=1: the four-wavefront shapes run on eight wavefronts (experiment)
     int two_sided;                     // -1: where only the four-wavefront kernels fit (default), 0: never, 1: always
     int64_t lds_bytes, lds_bytes_mw;   // one-wavefront kernels; four-wavefront kernels (+ the two-sided sweep's storage)
     double* prof;
@@ -129,18 +124,10 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     }
     h->mode = 0;
     h->two_sided = -1;
-    h->mw8 = false;
-    if (const char* e = getenv("OBCA_MW8")) {
-        if (atoi(e) == 1 && h->mw_ok && h->R_max <= 1536 && h->lds_bytes_mw + 256 <= 160 * 1024) {
-            const void* fn = h->R_max <= 1024 ? reinterpret_cast<const void*>(obca_ipm_kernel_mw8_r2) : reinterpret_cast<const void*>(obca_ipm_kernel_mw8_r3);
-            if (h->lds_bytes_mw <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_mw) == hipSuccess) h->mw8 = true;
-            else (void)hipGetLastError();
-        }
-    }
     if (const char* e = getenv("OBCA_TWO_SIDED")) { const int v = atoi(e); if (v >= -1 && v <= 1) h->two_sided = v; }
     if (const char* e = getenv("OBCA_MODE")) {
         const int m = atoi(e);                                     // out of range or not available for this shape: auto
-        if (m >= 0 && m <= 4 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok) && !(m == 4 && !(h->wave_ok && h->R_max <= 384))) h->mode = m;
+        if (m >= 0 && m <= 3 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok)) h->mode = m;
     }
     h->ws = nullptr; h->d_offm = nullptr;
     h->ws_stride = ((size_t)d->max_batch + 63) / 64 * 64;
@@ -167,8 +154,7 @@ extern "C" void obca_destroy(obca_handle* h) {
 }
 
 extern "C" int obca_set_mode(obca_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 4) return OBCA_E_INVAL;
-    if (mode == 4 && !(h->wave_ok && h->R_max <= 384 && h->lds_bytes + 64 <= 64 * 1024)) return OBCA_E_LDS;
+    if (!h || mode < 0 || mode > 3) return OBCA_E_INVAL;
     if (mode == 1 && !h->wave_ok) return OBCA_E_LDS;
     if (mode == 3 && !h->mw_ok) return OBCA_E_LDS;
     h->mode = mode;
@@ -282,36 +268,23 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     if (h->mode == 3 && !h->mw_ok) return OBCA_E_LDS;
     // one wavefront per instance where the rows fit its registers; four wavefronts (one CU) per instance for bigger
     // shapes that still fit the LDS; the lane kernel for everything else
-    if (h->mode == 4) {                              // two wavefronts per instance (experimental)
-        ObcaLaunch L2 = L;
-        L2.prm.opt.rho *= OBCA_RHO_ESCALATION;
-        if (h->R_max <= 256)
-            hipLaunchKernelGGL(obca_ipm_kernel_w2_r2, dim3(B), dim3(128), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
-        else
-            hipLaunchKernelGGL(obca_ipm_kernel_w2_r3, dim3(B), dim3(128), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
-        return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
-    }
     // (the choice depends on the SHAPE only, never on the batch size: the answer to an instance must not depend on how many
     // neighbours it was submitted with.  Measured: four wavefronts per instance would shorten launches of B <= 256 by 10-12 %,
     // tools/gpu_small_batch.py with OBCA_MODE=3 -- callers that want that latency ask for it, as the obca() class does)
     const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw || !lane) {
-        // the kernels run the escalated second solve of a free-time instance themselves, from their own descriptor
+        // the kernels run the recovery passes (penalty escalation, restart phase) themselves, from their own copy of the descriptor
         ObcaLaunch L2 = L;
-        L2.prm.opt.rho *= OBCA_RHO_ESCALATION;
-        if (mw && h->mw8)
-            hipLaunchKernelGGL(h->R_max <= 1024 ? obca_ipm_kernel_mw8_r2 : obca_ipm_kernel_mw8_r3, dim3(B), dim3(512),
-                               (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2);
-        else if (mw)
+        if (mw)
             hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
-                               (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2);
+                               (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2, L2);
         else if (h->R_max <= 256)
-            hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
+            hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2, L2);
         else if (h->R_max <= 320)
-            hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
+            hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2, L2);
         else
-            hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2);
+            hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2, L2);
     } else {
         if (!h->ws || !h->d_offm) {
             if (!h->ws && hipMalloc(&h->ws, sizeof(double) * (size_t)h->ws_doubles * h->ws_stride) != hipSuccess) { h->ws = nullptr; return OBCA_E_NOMEM; }

@@ -41,6 +41,12 @@
 #define OBCA_KAPPA_SOC 0.99
 #define OBCA_MAX_SOC 4
 #define OBCA_RHO_ESCALATION 100.0   /* obca_mpc4 only: one retry with rho x 100 when elastic variables remain */
+/* Restart phase (every variant; rule and measurements in oracle/ipm_dense.py:solve): a solve that ended without a feasible
+   point is repeated ONCE from the reference window -- poses = xref (first pose x0), inputs by differences clipped to their
+   box, free-time problem: the time scale at which the window is driven at this fraction of the speed bound -- with a
+   larger initial barrier parameter (IPOPT's restoration phase likewise raises mu to max(mu, ||c||_inf)). */
+#define OBCA_RESTART_MU 1.0
+#define OBCA_WINDOW_SPEED_FRAC 0.9
 
 /* Line-search filter capacity: a function of the problem SHAPE only, so that every kernel that can run a shape (and the
    oracles) stops at the same point when the filter fills up (status OBCA_STATUS_NUMERIC): 64 entries for shapes the

@@ -729,162 +729,6 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
     SYNC();
 }
 
-// ---------------------------------------------------------------- level 1, cooperative form (two-wavefront kernel)
-// FOUR lanes (one DPP quad) per (stage, obstacle) pair.  Lane q of the quad owns rows q, q+4, q+8 of the 10x10 block (22
-// doubles instead of the 55 of the whole lower triangle) and right-hand side column q of [G_x G_y G_theta rloc]; column j
-// of the elimination and the factor entries of the back substitution travel by quad broadcasts.  Every entry goes through
-// the same operations in the same order as in local_blocks below, so the two forms give bit-identical Y and Schur
-// complements -- at ~60 instead of ~135 doubles of registers, which is what lets two waves share a SIMD.
-#if OBCA_NT == 128
-template <int SRC>
-__device__ __forceinline__ double qbc(double v) { return dpp_move<SRC | (SRC << 2) | (SRC << 4) | (SRC << 6)>(v); }
-#define QBC(src, v) ((src) == 0 ? qbc<0>(v) : (src) == 1 ? qbc<1>(v) : (src) == 2 ? qbc<2>(v) : qbc<3>(v))
-
-__device__ int local_blocks_quad(const Lay& L, const Sh& S, const Inst& in, double dw, int lane) {
-    int bad = 0;
-    for (int w = lane; w < 4 * L.npair; w += NT) {
-        const int pr = w >> 2, q = w & 3;
-        const int k = pr / L.nO, i = pr - k * L.nO;
-        const int o0 = S.offm[i], m = S.offm[i + 1] - o0;
-        const double cs = S.ct[k], sn = S.st[k];
-        const double c0 = S.cc[2 * pr], c1 = S.cc[2 * pr + 1];
-        const double* pk = S.x + L.ip(k);
-        const double tx = pk[0] + cs * in.off, ty = pk[1] + sn * in.off;
-        const double yn = S.y[L.r_norm + pr], En = S.Einv[L.r_norm + pr];
-        const double yd = S.y[L.r_dist + pr], Ed = S.Einv[L.r_dist + pr];
-        const double nu1 = S.nu[2 * pr], nu2 = S.nu[2 * pr + 1];
-        const double dth = -sn * c0 + cs * c1;
-        double a0[OBCA_MAX_EDGES], a1[OBCA_MAX_EDGES], gn[OBCA_MAX_EDGES], gd[NW];
-#pragma unroll
-        for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
-            const bool on = j < m;
-            a0[j] = on ? S.Aobs[((size_t)k * L.M + o0 + j) * 2] : 0.0;
-            a1[j] = on ? S.Aobs[((size_t)k * L.M + o0 + j) * 2 + 1] : 0.0;
-            const double bj = on ? S.bobs[(size_t)k * L.M + o0 + j] : 0.0;
-            gn[j] = 2.0 * (a0[j] * c0 + a1[j] * c1);
-            gd[j] = on ? (tx * a0[j] + ty * a1[j] - bj) : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gd[OBCA_MAX_EDGES + j] = -in.gego[j];
-        // my rows: slot 0 = lambda row q, slot 1 = mu row 4 + q, slot 2 = rotation row 8 + q (q < 2)
-        double R[3][MW];
-        {
-            const bool on = q < m;                              // lambda slot q in use
-            const double a0a = on ? S.Aobs[((size_t)k * L.M + o0 + q) * 2] : 0.0;
-            const double a1a = on ? S.Aobs[((size_t)k * L.M + o0 + q) * 2 + 1] : 0.0;
-            const double bja = on ? S.bobs[(size_t)k * L.M + o0 + q] : 0.0;
-            const double gna = 2.0 * (a0a * c0 + a1a * c1);
-            const double gda = on ? (tx * a0a + ty * a1a - bja) : 0.0;
-            const double dia = on ? (dw + S.Einv[L.r_lam + k * L.M + o0 + (on ? q : 0)]) : 1.0;
-#pragma unroll
-            for (int b = 0; b < OBCA_MAX_EDGES; ++b) {
-                double v = Ed * gda * gd[b];
-                v += En * gna * gn[b] + yn * 2.0 * (a0a * a0[b] + a1a * a1[b]);
-                R[0][b] = v;
-            }
-            // diagonal of my lambda row: KP(j, j) += on ? dw + Einv : 1
-#pragma unroll
-            for (int b = 0; b < OBCA_MAX_EDGES; ++b) R[0][b] = (b == q) ? R[0][b] + dia : R[0][b];
-            const double gdm = -in.gego[q];                     // gd[4 + q]
-#pragma unroll
-            for (int b = 0; b < NW; ++b) R[1][b] = Ed * gdm * gd[b];
-            const double dim = dw + S.Einv[L.r_mu + k * 4 * L.nO + 4 * i + q];
-#pragma unroll
-            for (int b = OBCA_MAX_EDGES; b < NW; ++b) R[1][b] = (b == OBCA_MAX_EDGES + q) ? R[1][b] + dim : R[1][b];
-            // rotation rows (lanes 0 and 1)
-#pragma unroll
-            for (int b = 0; b < OBCA_MAX_EDGES; ++b) R[2][b] = (q == 0) ? cs * a0[b] + sn * a1[b] : -sn * a0[b] + cs * a1[b];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                R[2][OBCA_MAX_EDGES + j] = (q == 0) ? ((j == 0) ? 1.0 : (j == 2) ? -1.0 : 0.0) : ((j == 1) ? 1.0 : (j == 3) ? -1.0 : 0.0);
-            R[2][NW] = 0.0; R[2][NW + 1] = 0.0;
-        }
-        // my right-hand side column (q = 0, 1, 2: G_x, G_y, G_theta; q = 3: rloc)
-        double Gq[MW], Yv[MW];
-#pragma unroll
-        for (int j = 0; j < OBCA_MAX_EDGES; ++j) {
-            const bool on = j < m;
-            const double g0 = Ed * gd[j] * c0 + yd * a0[j];
-            const double g1 = Ed * gd[j] * c1 + yd * a1[j];
-            const double g2 = Ed * gd[j] * in.off * dth + yd * in.off * (-sn * a0[j] + cs * a1[j]) +
-                              nu1 * (-sn * a0[j] + cs * a1[j]) + nu2 * (-cs * a0[j] - sn * a1[j]);
-            const double g3 = on ? -S.bx[L.il(k) + o0 + (on ? j : 0)] : 0.0;
-            Gq[j] = q == 0 ? g0 : q == 1 ? g1 : q == 2 ? g2 : g3;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int a = OBCA_MAX_EDGES + j;
-            const double g0 = Ed * gd[a] * c0, g1 = Ed * gd[a] * c1, g2 = Ed * gd[a] * in.off * dth;
-            const double g3 = -S.bx[L.imu(k) + 4 * i + j];
-            Gq[a] = q == 0 ? g0 : q == 1 ? g1 : q == 2 ? g2 : g3;
-        }
-        Gq[NW] = q == 2 ? dth : q == 3 ? -S.crot[2 * pr] : 0.0;
-        Gq[NW + 1] = q == 2 ? -cs * c0 - sn * c1 : q == 3 ? -S.crot[2 * pr + 1] : 0.0;
-        // the original column waits in its slot of Y (LDS) until the Schur complement needs it again
-        double* Yo = S.Y + (size_t)pr * (MW * 4) + q;
-#pragma unroll
-        for (int a = 0; a < MW; ++a) { Yv[a] = Gq[a]; Yo[4 * a] = Gq[a]; }
-        // LDL^T without pivoting, forward substitution fused; column j comes by quad broadcast from the rows' owners.  The
-        // reciprocal pivot replaces the pivot in its owner's row (the back substitution fetches it from there).
-        int nneg = 0;
-#pragma unroll
-        for (int j = 0; j < MW; ++j) {
-            const double d = QBC(j & 3, R[j >> 2][j]);
-            const double dinv = 1.0 / d;
-            nneg += dinv < 0.0 ? 1 : 0;
-            if (!(fabs(dinv) < INFINITY)) bad = 1;              // zero or NaN pivot
-            double cb[MW];                                       // K[b][j], b > j, unscaled
-#pragma unroll
-            for (int b = 0; b < MW; ++b)
-                if (b > j) cb[b] = QBC(b & 3, R[b >> 2][j]);
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                // my row a = 4 sl + q: rows above j are updated
-                const int abase = 4 * sl;
-                const double la = R[sl][j] * dinv;
-#pragma unroll
-                for (int b = 0; b < MW; ++b) {
-                    if (b > j && b <= abase + 3) {
-                        const bool act = (abase + q > j) && (b <= abase + q);
-                        const double upd = R[sl][b] - la * cb[b];
-                        R[sl][b] = act ? upd : R[sl][b];
-                    }
-                }
-                if (abase + 3 >= j && abase <= j) R[sl][j] = (abase + q > j) ? la : (abase + q == j) ? dinv : R[sl][j];
-                else if (abase > j) R[sl][j] = la;                // KP(a, j) *= dinv[j]
-            }
-#pragma unroll
-            for (int a = 0; a < MW; ++a)
-                if (a > j) Yv[a] -= (cb[a] * dinv) * Yv[j];
-        }
-        if (nneg != 2) bad = 1;
-#pragma unroll
-        for (int jj = 0; jj < MW; ++jj) {
-            const int j = MW - 1 - jj;
-            double v = Yv[j] * QBC(j & 3, R[j >> 2][j]);
-#pragma unroll
-            for (int a = 0; a < MW; ++a)
-                if (a > j) v -= QBC(a & 3, R[a >> 2][j]) * Yv[a];
-            Yv[j] = v;
-        }
-        // my column of the Schur complement G'Y (G_x, G_y, G_theta from lanes 0, 1, 2), then of Y = Kloc^-1 [G | rloc]
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int e = 0; e < MW; ++e) {
-            const double ge = Yo[4 * e];
-            s0 += qbc<0>(ge) * Yv[e];
-            s1 += qbc<1>(ge) * Yv[e];
-            s2 += qbc<2>(ge) * Yv[e];
-        }
-#pragma unroll
-        for (int a = 0; a < MW; ++a) Yo[4 * a] = Yv[a];
-        double* So = S.Sloc + (size_t)pr * 12 + q;
-        So[0] = s0; So[4] = s1; So[8] = s2;
-    }
-    return bad;
-}
-#endif
-
 // ---------------------------------------------------------------- level 1: local blocks, one lane per pair
 // Writes Y[pr] = Kloc^-1 [G | rloc] (MW x 4) and Sloc[pr] = (G^T Y_G (3x3), G^T Y_r (3)). Returns 1 on a
 // wrong-sign pivot.
@@ -893,14 +737,9 @@ __device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw
 #ifdef NO_LOCAL
     return 0;
 #endif
-#if OBCA_NT == 128
-    bad = local_blocks_quad(L, S, in, dw, lane);
-    for (int w = 0; w < 0; ++w) {
-#else
     // TWO lanes per pair: both factor the block (registers), each solves two of the four right-hand sides
     // [G_x G_y | G_theta rloc] and produces the matching columns of Y and of the Schur complement G'Y.
     for (int w = lane; w < 2 * L.npair; w += NT) {
-#endif
         const int pr = w >> 1;
         const bool hi = (w & 1) != 0;
         const int k = pr / L.nO, i = pr - k * L.nO;
@@ -1451,9 +1290,6 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
             }
             lu3_solve(lu, t3[0], t3[1], t3[2], yp[0], yp[1], yp[2]);
             lu3_solve(lu, u3[0], u3[1], u3[2], s2[0], s2[1], s2[2]);
-#if OBCA_NT == 128
-            __asm__ volatile("" ::: "memory");     // (256-register build only: keeps the second half's loads behind the first half's uses)
-#endif
 #pragma unroll
             for (int i = 0; i < 18; ++i) Pb[i] = Pl[18 + i];
             double fa[6];
@@ -1699,6 +1535,35 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
     return 0;
 }
 
+// Start point of the restart phase (oracle/ipm_dense.py:window_start): poses of the reference window (first pose x0), inputs
+// by differences clipped to their box, free-time problem (iT >= 0): the time scale at which the window is driven at
+// OBCA_WINDOW_SPEED_FRAC of the speed bound; lambda = mu = 0 (x is zero on entry).  Rare, one lane, out of line with scalar
+// arguments only: inlined into the body it cost the four-wavefront kernels 400 B of scratch.
+__device__ __noinline__ void window_start_point(double* x, const double* xref, const Inst* inp, int N, int NS, int iT) {
+    const Inst& in = *inp;
+    const int N1 = N + 1;
+    double len = 0.0;
+    for (int k = 0; k <= N; ++k) {
+        for (int j = 0; j < 3; ++j) x[k * NS + j] = (k == 0) ? in.x0[j] : xref[j * N1 + k];
+        if (k > 0) {
+            const double ddx = x[k * NS] - x[(k - 1) * NS], ddy = x[k * NS + 1] - x[(k - 1) * NS + 1];
+            len += sqrt(ddx * ddx + ddy * ddy);
+        }
+    }
+    double h = in.Ts;
+    if (iT >= 0) {
+        const double T0 = fmin(fmax(1.0, len / (N * OBCA_WINDOW_SPEED_FRAC * in.uU[0] * in.Ts)), fmax(1.0, in.Tmax));
+        x[iT] = T0;
+        h *= T0;
+    }
+    for (int k = 0; k < N; ++k) {
+        const double ddx = x[(k + 1) * NS] - x[k * NS], ddy = x[(k + 1) * NS + 1] - x[k * NS + 1];
+        const double dth = x[(k + 1) * NS + 2] - x[k * NS + 2];
+        x[k * NS + 3] = fmin(fmax(sqrt(ddx * ddx + ddy * ddy) / h, in.uL[0]), in.uU[0]);
+        x[k * NS + 4] = fmin(fmax(dth / h, in.uL[1]), in.uU[1]);
+    }
+}
+
 }  // namespace
 
 // ================================================================== the kernel
@@ -1755,12 +1620,24 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             return;
         }
     }
-    // Penalty escalation (one, free-time problem only): the l1 penalty is exact only while rho exceeds the multipliers.
-    // If obca_mpc4 converges with elastic variables left -- what "infeasible" looks like, but also what a too small rho
-    // looks like (the open-loop problem of demo1 at N = 10) -- the caller runs the body a second time (pass = 1) with
-    // rho x 100; every other instance returns here (same rule in oracle/ipm_dense.py:solve).  A genuinely infeasible problem stays
-    // infeasible; the fixed-time variants are not escalated, the reference has its obca_mpc6 -> obca_mpc8 fallback.
-    if (pass && !(A.variant[inst] == 4 && A.status[inst] == OBCA_STATUS_INFEASIBLE)) return;
+    // The caller runs the body up to three times per instance (same rule in oracle/ipm_dense.py:solve):
+    //   pass 0  the reference's cold start (or the caller's optional warm start);
+    //   pass 1  penalty escalation, free-time problem only: the l1 penalty is exact only while rho exceeds the multipliers.
+    //           If obca_mpc4 converged with elastic variables left -- what "infeasible" looks like, but also what a too small
+    //           rho looks like (the open-loop problem of demo1 at N = 10) -- once more from the cold start with rho x 100;
+    //   pass 2  restart phase, every variant: a solve that still has no feasible point (infeasible stationary point of the
+    //           penalty problem, line-search failure, iteration limit, filter full) is repeated from the reference window
+    //           with barrier parameter OBCA_RESTART_MU.
+    // Every other instance returns here.  A genuinely infeasible problem stays infeasible.
+    double rho_mult = 1.0;
+    bool from_window = false;
+    if (pass) {
+        const int st0 = __builtin_amdgcn_readfirstlane(A.status[inst]);     // wave-uniform: the flags below stay scalar
+        const bool esc = A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE;
+        if (pass == 1) { if (!esc) return; }
+        else { if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 == OBCA_STATUS_BAD_BOUNDS) return; from_window = true; }
+        if (esc) rho_mult = OBCA_RHO_ESCALATION;
+    }
 
     // ---- layout ------------------------------------------------------------------------------------
     Lay L;
@@ -1851,15 +1728,14 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     SYNC();
 
     ObcaOptsDev O;
-    O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed; O.max_soc = Ain.prm.opt.max_soc;          // by value: A may live in HBM (fused closed-loop kernel); the descriptor of
-                                              // an escalated pass carries rho x 100 itself
+    O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho * rho_mult; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed; O.max_soc = Ain.prm.opt.max_soc;          // by value: A may live in HBM (fused closed-loop kernel)
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
 
     // ---- start point: zeros, Topt = 1 (obca.py:856) -- or, when the caller asked for it (obca_set_warm_start; the
     // reference never does), the previous solve's primal vector moved one stage forward (last stage repeated)
-    const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
+    const bool warm = !from_window && A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
     if (warm) {
         const double* zp = A.warm_z + (size_t)inst * A.n_max;
         const int blk = L.NS - 2;                              // pose, lambda, mu of a stage (inputs handled apart)
@@ -1881,6 +1757,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     for (int t = lane; t < 2 * L.npair; t += NT) S.nu[t] = 0.0;
     SYNC();
     if (!warm && L.free_T && lane == 0) S.x[L.iT()] = 1.0;
+    if (from_window && lane == 0) window_start_point(S.x, S.xref, &in, L.N, L.NS, L.free_T ? L.iT() : -1);
     SYNC();
     int status = OBCA_STATUS_MAXITER;
     int it = 0, nfact = 0;
@@ -1909,7 +1786,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     SYNC();
     f0 = eval_objective<true>(L, S, in, S.x, sf, lane);
     PUT(IV_F, f0);
-    double mu = warm ? A.warm_mu : OBCA_MU_INIT;
+    double mu = from_window ? OBCA_RESTART_MU : (warm ? A.warm_mu : OBCA_MU_INIT);
     // rows: bounds, slacks with bound push, elastic variables on their 1-d central path
     Rows<RPL> W;
     {
@@ -2459,23 +2336,32 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
 }
 
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
-// The solve and, for a free-time instance that ended "infeasible", the escalated solve: two inlined copies of the
-// body, the second one cold.  The second copy reads its OWN descriptor (A2 = A with rho x 100, a second kernel
-// argument): were both copies to read A, the compiler would merge their identical prologue expressions and keep those
-// values alive across the whole first solve, which showed up as scratch traffic in the hot copy.
+// The solve and, for the instances that need them, the recovery passes (penalty escalation, restart phase): three inlined
+// copies of the body -- the hot one (pass 0) and two cold ones (passes 1 and 2) that return at once where they do not
+// apply.  Every copy reads its OWN descriptor (A2, A3 = further kernel arguments with the same content): were they all
+// to read A, the compiler would merge their identical prologue expressions and keep those values alive across the whole
+// first solve, which showed up as scratch traffic in the hot copy.
 template <int RPL>
-__device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const ObcaLaunch& A2) {
+__device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const ObcaLaunch& A2, const ObcaLaunch& A3) {
     const int inst = blockIdx.x;
     obca_ipm_body<RPL>(A, inst, 0);
     if (inst >= A.B) return;
     __syncthreads();                                            // status written by thread 0 of this workgroup
-    if (A2.variant[inst] == 4 && A2.status[inst] == OBCA_STATUS_INFEASIBLE) obca_ipm_body<RPL>(A2, inst, 1);
+    {
+        const int st = A2.status[inst];
+        if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing to recover
+    }
+    // (straight-line, not a loop over the passes: around a loop the compiler hoists the descriptor loads of the cold copy and
+    // the kernel needs 64-256 B of scratch; measured with tools/kernel_resources.py)
+    obca_ipm_body<RPL>(A2, inst, 1);
+    __syncthreads();
+    obca_ipm_body<RPL>(A3, inst, 2);
 }
 
 #if OBCA_NT == 64
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<4>(A, A2); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<5>(A, A2); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<6>(A, A2); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<4>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<6>(A, A2, A3); }
 
 // ================================================================== fused closed loop
 // One wavefront runs one step of one rollout at a time: lane 0 runs the harness of csrc/obca_rollout_core.h around
@@ -2573,22 +2459,23 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
         const int g = __builtin_amdgcn_readfirstlane(ro_msg[1]);     // wave-uniform: the descriptor is read with scalar loads
         __syncthreads();
         if (running) {
-            for (int attempt = 0; attempt < 2; ++attempt) {
-                // second attempt: obca_mpc4 -> the escalated pass (rho x 100; returns at once unless the first pass ended
-                // "infeasible"); obca_mpc6 -> obca_mpc8 where obca_mpc6 failed.  One call site: the body is inlined once.
+            // attempts 0..2: the three passes of the solve (cold start, penalty escalation, restart phase -- the body returns
+            // at once where a pass does not apply); attempts 3..5: the same for obca_mpc8 where obca_mpc6 failed (src/closed_loop.py:393-398).
+            // One call site: the body is inlined once.
+            for (int attempt = 0; attempt < 6; ++attempt) {
                 const ObcaLaunch* Lp = launches + g;
-                if (attempt == 1) {
-                    if (g == 0) Lp = launches + 2 * rollout::MAX_GROUPS;
-                    else {
+                if (attempt >= 3) {
+                    if (g == 0) break;
+                    if (attempt == 3) {
                         if (lane == 0) ro_msg[0] = ro_retry(&D, g, b);
                         __syncthreads();
                         const int v8 = ro_msg[0];
                         __syncthreads();
                         if (v8 != 8) break;
-                        Lp = launches + g + rollout::MAX_GROUPS;
                     }
+                    Lp = launches + g + rollout::MAX_GROUPS;
                 }
-                obca_ipm_body<RPL, false, ObcaLaunchConst>(*(ObcaLaunchConst*)Lp, b, (attempt == 1 && g == 0) ? 1 : 0);
+                obca_ipm_body<RPL, false, ObcaLaunchConst>(*(ObcaLaunchConst*)Lp, b, attempt >= 3 ? attempt - 3 : attempt);
                 __syncthreads();
             }
             if (lane == 0) ro_finish(&D, b);
@@ -2634,16 +2521,8 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches,
     rollout_fused_body<6>(*Dp, launches, n_steps, sched);
 }
 
-#elif OBCA_NT == 128
-// two wavefronts per instance, two workgroups' worth of waves per SIMD (register budget capped at 256): rows r = thread + 128 j
-extern "C" __global__ void __launch_bounds__(OBCA_NT, 2) obca_ipm_kernel_w2_r2(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<2>(A, A2); }
-extern "C" __global__ void __launch_bounds__(OBCA_NT, 2) obca_ipm_kernel_w2_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
-#elif OBCA_NT == 512
-// eight wavefronts per instance (two per SIMD, register budget 256): rows r = thread + 512 j, j < 2 (up to 1024 rows) or j < 3 (1536)
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw8_r2(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<2>(A, A2); }
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw8_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
 #else
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<3>(A, A2); }
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2) { solve_with_escalation<5>(A, A2); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<3>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5>(A, A2, A3); }
 #endif

@@ -992,9 +992,10 @@ LPI_FN double row_barrier_lpi(double lo, double up, bool eq, double s, double p,
 struct Out { int status, iters, nfact; double f, elastic, E0, ts_opt, sf; };
 
 // zwarm != nullptr: start from that primal vector moved one stage forward (last stage repeated) with barrier
-// parameter mu_warm (obca_set_warm_start); otherwise the reference's cold start
+// parameter mu_warm (obca_set_warm_start); otherwise the reference's cold start, or -- restart phase, from_window --
+// the reference window as a trajectory (oracle/ipm_dense.py:window_start) with barrier parameter mu_warm
 LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaOptsDev& O,
-                          const double* zwarm = nullptr, double mu_warm = OBCA_MU_INIT) {
+                          const double* zwarm = nullptr, double mu_warm = OBCA_MU_INIT, bool from_window = false) {
     const int max_iter = L.free_T ? O.max_iter_free : O.max_iter_fixed;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
@@ -1014,6 +1015,26 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
     } else {
         for (int t = 0; t < L.n; ++t) S.x[t] = 0.0;
         if (L.free_T) S.x[L.iT()] = 1.0;
+        if (from_window) {              // poses of the reference window, inputs by differences
+            const int N1 = L.N + 1;
+            for (int k = 0; k <= L.N; ++k)
+                for (int j = 0; j < 3; ++j) S.x[L.ip(k) + j] = (k == 0) ? in.x0[j] : S.xref[j * N1 + k];
+            if (L.free_T) {             // time scale at which the window is driven at OBCA_WINDOW_SPEED_FRAC of the speed bound
+                double len = 0.0;
+                for (int k = 0; k < L.N; ++k) {
+                    const double ddx = S.x[L.ip(k + 1)] - S.x[L.ip(k)], ddy = S.x[L.ip(k + 1) + 1] - S.x[L.ip(k) + 1];
+                    len += sqrt(ddx * ddx + ddy * ddy);
+                }
+                S.x[L.iT()] = fmin(fmax(1.0, len / (L.N * OBCA_WINDOW_SPEED_FRAC * in.uU[0] * in.Ts)), fmax(1.0, in.Tmax));
+            }
+            const double h = in.Ts * (L.free_T ? S.x[L.iT()] : 1.0);
+            for (int k = 0; k < L.N; ++k) {
+                const double ddx = S.x[L.ip(k + 1)] - S.x[L.ip(k)], ddy = S.x[L.ip(k + 1) + 1] - S.x[L.ip(k) + 1];
+                const double dth = S.x[L.ip(k + 1) + 2] - S.x[L.ip(k) + 2];
+                S.x[L.iu(k)] = fmin(fmax(sqrt(ddx * ddx + ddy * ddy) / h, in.uL[0]), in.uU[0]);
+                S.x[L.iu(k) + 1] = fmin(fmax(dth / h, in.uL[1]), in.uU[1]);
+            }
+        }
     }
     for (int t = 0; t < 2 * L.npair; ++t) S.nu[t] = 0.0;
     Out o;
@@ -1029,7 +1050,7 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
         rho = O.rho * sf;
     }
     f = eval_objective<true>(L, S, in, S.x, sf, 0);
-    double mu = zwarm ? mu_warm : OBCA_MU_INIT;
+    double mu = (zwarm || from_window) ? mu_warm : OBCA_MU_INIT;
     bool bad_bounds = false;
     for (int r = 0; r < L.R; ++r) {
         double lo, up;
@@ -1432,6 +1453,15 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
         O2.rho *= OBCA_RHO_ESCALATION;
         const Out o1 = o;
         o = solve_instance(L, S, in, O2, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
+        o.iters += o1.iters; o.nfact += o1.nfact;
+    }
+    if (!(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
+        // restart phase (every variant; oracle/ipm_dense.py:solve): the solve has not reached a feasible point from the
+        // reference's cold start -- once more from the reference window, barrier parameter OBCA_RESTART_MU
+        ObcaOptsDev O3 = A.prm.opt;
+        if (L.free_T && o.status == OBCA_STATUS_INFEASIBLE) O3.rho *= OBCA_RHO_ESCALATION;
+        const Out o1 = o;
+        o = solve_instance(L, S, in, O3, nullptr, OBCA_RESTART_MU, true);
         o.iters += o1.iters; o.nfact += o1.nfact;
     }
     if (A.warm_z != nullptr && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE)) {

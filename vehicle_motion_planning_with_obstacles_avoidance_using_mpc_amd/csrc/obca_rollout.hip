@@ -49,7 +49,7 @@ struct obca_rollouts {
     int32_t* sched;           /* [2 + B] work queue of the fused kernel: next item, abort flag, rounds done per rollout */
     int n_slots;              /* workgroups the device holds at once (one per SIMD) */
     int sched_mode;           /* 1: step-granular work queue (default), 0: one workgroup per rollout (OBCA_ROLLOUT_QUEUE=0) */
-    ObcaLaunch hL[2 * rollout::MAX_GROUPS + 1];        // [2*MAX_GROUPS] = escalated pass of group 0 (obca_mpc4): rho x 100
+    ObcaLaunch hL[2 * rollout::MAX_GROUPS];            // [g]: obca_mpc4 (g = 0) / obca_mpc6, [g + MAX_GROUPS]: obca_mpc8 where obca_mpc6 failed
     bool fused_ok;
     int32_t rows_max;
     int64_t lds_max;
@@ -146,7 +146,7 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     }
     if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
     r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0; r->warm_mu = 0.0;
-    if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS + 1))) rc = OBCA_E_NOMEM;
+    if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS))) rc = OBCA_E_NOMEM;
     r->sched = nullptr; r->n_slots = 1024; r->sched_mode = 1;
     if (rc == OBCA_OK && !dev_alloc(r, r->sched, (size_t)d->batch + 2 + 4 * 4096)) rc = OBCA_E_NOMEM;   // (+ per-workgroup statistics of -DOBCA_RO_STATS builds)
     {
@@ -217,8 +217,6 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
             if (g > 0) r->hL[g + a * rollout::MAX_GROUPS].R_max -= 3;
             if (r->hL[g + a * rollout::MAX_GROUPS].R_max > r->rows_max) r->rows_max = r->hL[g + a * rollout::MAX_GROUPS].R_max;
         }
-    r->hL[2 * rollout::MAX_GROUPS] = r->hL[0];
-    r->hL[2 * rollout::MAX_GROUPS].prm.opt.rho *= OBCA_RHO_ESCALATION;
     if (hipMemcpyAsync(r->dD, &r->D, sizeof(rollout::Dev), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(r->dL, r->hL, sizeof(r->hL), hipMemcpyHostToDevice, s) != hipSuccess)
         return OBCA_E_HIP;

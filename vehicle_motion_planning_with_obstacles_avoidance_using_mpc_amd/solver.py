@@ -87,7 +87,7 @@ class BatchSolver:
         if mode is not None:
             self.set_mode(mode)
 
-    MODES = {"auto": 0, "wave": 1, "lane": 2, "multiwave": 3, "twowave": 4}
+    MODES = {"auto": 0, "wave": 1, "lane": 2, "multiwave": 3}
 
     def set_mode(self, mode):
         """'auto' | 'wave' (one wavefront per instance, LDS) | 'multiwave' (four wavefronts per instance, LDS) |
