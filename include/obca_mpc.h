@@ -58,7 +58,7 @@ typedef struct obca_params {
     double rho;                        /* [1e4]   elastic (l1) penalty, unscaled objective units; a free-time solve
                                                    that ends with elastic variables left is repeated once with
                                                    rho x 100 (exact-penalty escalation)                      */
-    /* Recovery (not an option): a solve that ends without a feasible point -- status 2, -1, -2, -3 -- is repeated once from
+    /* Recovery: a solve that ends without a feasible point -- status 2, -1, -2, -3 -- is repeated once from
        the reference window xref (poses = xref, first pose x0; inputs by differences) instead of the reference's all-zero
        start, inside the same launch ("restart phase"; rule and measurements: oracle/ipm_dense.py:solve).  The status,
        iteration and factorisation counts returned are those of the whole sequence. */
@@ -67,6 +67,9 @@ typedef struct obca_params {
     int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8                       */
     int32_t max_soc;                   /* [4]     IPOPT max_soc: second-order-correction trials after a rejected first
                                                    trial step; 0 = the default, negative = off              */
+    int32_t restart;                   /* [on]    restart phase (see above); 0 = the default (on), negative = off -- what a
+                                                   driver asks for where its own fallback follows, as obca_mpc8 follows a failed
+                                                   obca_mpc6 in the closed loop (src/closed_loop.py:393-398)  */
 } obca_params;
 
 typedef struct obca_handle obca_handle;

@@ -16,7 +16,8 @@ class OracleParams(ctypes.Structure):
                                                       ("ego", 4))] + \
                [("dmin", ctypes.c_double), ("tol", ctypes.c_double), ("rho", ctypes.c_double),
                 ("feas_tol", ctypes.c_double), ("max_iter_free", ctypes.c_int), ("max_iter_fixed", ctypes.c_int),
-                ("max_soc", ctypes.c_int)]          # 0 = IPOPT's default (4 second-order-correction trials), < 0 = off
+                ("max_soc", ctypes.c_int),          # 0 = IPOPT's default (4 second-order-correction trials), < 0 = off
+                ("restart", ctypes.c_int)]          # 0 = default (restart phase on), < 0 = off
 
 
 _lib = None
@@ -60,6 +61,7 @@ def default_params(**kw):
     p.max_iter_free = int(kw.get("max_iter_free", 0))
     p.max_iter_fixed = int(kw.get("max_iter_fixed", 0))
     p.max_soc = int(kw.get("max_soc", 0))
+    p.restart = int(kw.get("restart", 0))
     return p
 
 

@@ -785,6 +785,7 @@ typedef struct {
     double xL[2], xU[2], uL[2], uU[2], ego[4], dmin, tol, rho, feas_tol;
     int max_iter_free, max_iter_fixed;
     int max_soc;                            /* 0 = IPOPT's default (4), negative = off */
+    int restart;                            /* 0 = default (restart phase on), negative = off */
 } OracleParams;
 
 static void sym(double* d, const double* s, int k) { for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) d[k * a + b] = 0.5 * (s[k * a + b] + s[k * b + a]); }
@@ -849,7 +850,7 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
             iters[q] += it1;
             if (info) info[(size_t)q * 4 + 3] += nf1;
         }
-        if (!(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
+        if (prm->restart >= 0 && !(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
             /* restart phase (oracle/ipm_dense.py:solve): once more from the reference window, mu = RESTART_MU */
             Opts o3 = o;
             if (p.variant == 4 && status[q] == ST_INFEASIBLE) o3.rho = o.rho * 100.0;

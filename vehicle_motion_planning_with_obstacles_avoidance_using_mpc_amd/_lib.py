@@ -29,7 +29,8 @@ class ObcaParams(ctypes.Structure):
                 ("uL", ctypes.c_double * 2), ("uU", ctypes.c_double * 2),
                 ("ego", ctypes.c_double * 4), ("dmin", ctypes.c_double),
                 ("tol", ctypes.c_double), ("rho", ctypes.c_double), ("feas_tol", ctypes.c_double),
-                ("max_iter_free", ctypes.c_int32), ("max_iter_fixed", ctypes.c_int32), ("max_soc", ctypes.c_int32)]
+                ("max_iter_free", ctypes.c_int32), ("max_iter_fixed", ctypes.c_int32), ("max_soc", ctypes.c_int32),
+                ("restart", ctypes.c_int32)]
 
 
 class ObcaRolloutDims(ctypes.Structure):

@@ -27,6 +27,11 @@ class closedLoop:
             from .obca import obca
             solver = obca()
         self.obca_solver = solver
+        # this driver answers a failed obca_mpc6 with obca_mpc8 itself (step(), mpc_openLoop_fixTime), so it asks the solver
+        # object -- where it offers the switch -- to skip the restart phase of obca_mpc6 (include/obca_mpc.h: restart); the
+        # device-resident rollouts do the same (csrc/obca_rollout.hip)
+        if hasattr(solver, "restart_obca_mpc6"):
+            solver.restart_obca_mpc6 = False
         st = self.setting
         self.path_solver = a_star(st.org_gridMap, (st.startPose[1], st.startPose[0]), (st.goalPose[1], st.goalPose[0]))
         # constants of src/closed_loop.py:32-101
@@ -276,6 +281,8 @@ class BatchClosedLoop:
         a0 = calls[0][2]
         free = calls[0][1] == 4
         kw = dict(xL=a0[6], xU=a0[7], uL=a0[8], uU=a0[9], ego=a0[16], dmin=a0[15])
+        if calls[0][1] == 6:
+            kw["restart"] = -1               # obca_mpc8 follows a failed obca_mpc6 (step()): no restart phase for it
         prm = self._SolverParams(Q_free=a0[2], R_free=a0[3], P_free=a0[1], **kw) if free else \
             self._SolverParams(Q_fix=a0[2], R_fix=a0[3], P_fix=a0[1], **kw)
         st = lambda j: np.stack([p[j] for p in packed])
@@ -294,7 +301,7 @@ class BatchClosedLoop:
             # one launch = one set of solver constants: weights, boxes, footprint and clearance are part of the key
             const = tuple(np.asarray(args[j], float).round(15).tobytes() for j in (1, 2, 6, 7, 8, 9, 16)) + \
                 tuple(np.asarray(r, float).tobytes() for r in args[3]) + (float(args[15]),)
-            groups.setdefault((variant == 4, args[4], m, const), []).append((idx, variant, args))
+            groups.setdefault((variant, args[4], m, const), []).append((idx, variant, args))
         results = {}
         for calls in groups.values():
             for (idx, _, _), res in zip(calls, self._solve_group(calls)):

@@ -58,7 +58,7 @@
 #define OBCA_ZK_DOUBLES(N) (36 * (((N) + 1) / 2) + 42)   /* four-wavefront kernels: forward half of the two-sided Riccati sweep */
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
-struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc; };
+struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, restart; };
 struct ObcaParamsDev {
     ObcaWeightsDev free_time, fixed_time;
     double xL[2], xU[2], uL[2], uU[2];

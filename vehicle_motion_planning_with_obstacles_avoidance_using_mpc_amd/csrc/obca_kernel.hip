@@ -1635,7 +1635,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         const int st0 = __builtin_amdgcn_readfirstlane(A.status[inst]);     // wave-uniform: the flags below stay scalar
         const bool esc = A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE;
         if (pass == 1) { if (!esc) return; }
-        else { if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 == OBCA_STATUS_BAD_BOUNDS) return; from_window = true; }
+        else { if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 == OBCA_STATUS_BAD_BOUNDS || Ain.prm.opt.restart == 0) return; from_window = true; }
         if (esc) rho_mult = OBCA_RHO_ESCALATION;
     }
 

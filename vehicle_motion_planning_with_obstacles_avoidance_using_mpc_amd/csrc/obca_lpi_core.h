@@ -1455,7 +1455,7 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
         o = solve_instance(L, S, in, O2, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
         o.iters += o1.iters; o.nfact += o1.nfact;
     }
-    if (!(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
+    if (A.prm.opt.restart && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
         // restart phase (every variant; oracle/ipm_dense.py:solve): the solve has not reached a feasible point from the
         // reference's cold start -- once more from the reference window, barrier parameter OBCA_RESTART_MU
         ObcaOptsDev O3 = A.prm.opt;

@@ -17,6 +17,9 @@ from .solver import BatchSolver, SolverParams, pack_reference_call
 class obca:
     def __init__(self):
         self._solvers = {}
+        # the restart phase of obca_mpc6 (include/obca_mpc.h: restart).  On for a bare call; a driver that answers a failed
+        # obca_mpc6 with obca_mpc8 itself (this package's closedLoop) switches it off
+        self.restart_obca_mpc6 = True
 
     def _solver(self, N, m):
         key = (int(N), tuple(m))
@@ -34,6 +37,8 @@ class obca:
         m, x0v, u0v, xr, A, b, Tsv, term = pack_reference_call(variant, Ts, N, x0, xref, nObs, vObs, AObs, bObs, u0,
                                                                 terminal_set)
         kw = dict(xL=xL, xU=xU, uL=uL, uU=uU, ego=ego, dmin=dmin)
+        if variant == 6 and not self.restart_obca_mpc6:
+            kw["restart"] = -1
         if variant == 4:
             prm = SolverParams(Q_free=Q, R_free=R, P_free=P, **kw)
         else:

@@ -21,7 +21,7 @@ class SolverParams:
     def __init__(self, xL=(0.0, 0.0), xU=(39.0, 10.0), uL=(-0.6, -math.pi / 6), uU=(0.6, math.pi / 6),
                  ego=DEFAULT_EGO, dmin=0.05,
                  Q_free=None, R_free=None, P_free=None, Q_fix=None, R_fix=None, P_fix=None,
-                 tol=0.0, rho=0.0, feas_tol=0.0, max_iter_free=0, max_iter_fixed=0, max_soc=0):
+                 tol=0.0, rho=0.0, feas_tol=0.0, max_iter_free=0, max_iter_fixed=0, max_soc=0, restart=0):
         self.xL, self.xU, self.uL, self.uU = [tuple(float(v) for v in a[:2]) for a in (xL, xU, uL, uU)]
         self.ego = tuple(float(v) for v in ego)
         self.dmin = float(dmin)
@@ -35,6 +35,7 @@ class SolverParams:
         self.tol, self.rho, self.feas_tol = float(tol), float(rho), float(feas_tol)
         self.max_iter_free, self.max_iter_fixed = int(max_iter_free), int(max_iter_fixed)
         self.max_soc = int(max_soc)            # 0 = IPOPT's default (4), negative = no second-order correction
+        self.restart = int(restart)            # 0 = restart phase on (default), negative = off (include/obca_mpc.h)
 
     def to_c(self):
         p = _lib.ObcaParams()
@@ -50,6 +51,7 @@ class SolverParams:
         p.tol, p.rho, p.feas_tol = self.tol, self.rho, self.feas_tol
         p.max_iter_free, p.max_iter_fixed = self.max_iter_free, self.max_iter_fixed
         p.max_soc = self.max_soc
+        p.restart = self.restart
         return p
 
 
