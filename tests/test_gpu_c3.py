@@ -103,7 +103,7 @@ def test_c3_shapes_run_on_the_lds_kernel_and_agree_with_the_lane_kernel():
         a, m, l = run(b, 20), run(b, 20, "multiwave"), run(b, 20, "lane")
         assert np.array_equal(a["xopt"], m["xopt"]) and np.array_equal(a["iters"], m["iters"])      # auto == multiwave
         both = np.isin(m["status"], (0, 1)) & np.isin(l["status"], (0, 1))
-        assert both.mean() > (0.7 if gated else 0.9)
+        assert both.mean() > (0.93 if gated else 0.97)          # measured at 8192: 99.6 % / 100 % (bench.py config_c3)
         # two implementations of one algorithm (different expression forms => different roundoff): on a 150-190-iteration
         # non-convex run a flipped decision may end in another status; the feasibility verdict must agree almost everywhere
         assert (np.isin(m["status"], (0, 1)) != np.isin(l["status"], (0, 1))).sum() <= (3 if gated else 1)
@@ -116,6 +116,23 @@ def test_c3_shapes_run_on_the_lds_kernel_and_agree_with_the_lane_kernel():
             assert dynamics_residual(o["xopt"], o["uopt"], o["ts_opt"])[both].max() < 1e-7
         close = np.abs(m["xopt"] - l["xopt"]).reshape(len(both), -1).max(1) < 1e-5
         assert (close & both).sum() >= 0.9 * both.sum()
+
+
+def test_one_sided_sweep_is_the_lane_kernels_iterate_sequence():
+    """with the sweep one-sided (obca_set_two_sided_sweep(h, 0)) the four-wavefront kernel and the lane kernel run
+    the same algorithm with the same elimination order -- the strict form of the comparison above: same status on EVERY
+    instance, same iteration count on most, 1e-8 where the counts agree.  (The two-sided default is checked per instance
+    through KKT certificates: tests/test_gpu_certificates.py::test_c3_instances_are_certified_at_N20.)"""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    for gated in (False, True):
+        b = sc.make_batch_c3(48, 20, gated=gated)
+        m, l = run(b, 20, "multiwave", two_sided=False), run(b, 20, "lane")
+        assert np.array_equal(np.isin(m["status"], (0, 1)), np.isin(l["status"], (0, 1)))
+        assert (m["status"] != l["status"]).sum() <= 1            # the KIND of a failure may differ on a roundoff-sensitive path
+        both = np.isin(m["status"], (0, 1))
+        same = both & (m["iters"] == l["iters"])
+        assert same.sum() >= (0.5 if gated else 0.85) * both.sum()
+        assert np.abs(m["xopt"] - l["xopt"])[same].max() < 1e-8
 
 
 def test_c3_free_time_N20_matches_oracle():
@@ -153,8 +170,8 @@ def test_c3_fixed_time_moving_obstacles():
         b8["variant"] = np.full(int(fail.sum()), 8, dtype=np.int32)
         o8 = run(b8, N)
         ok8 = (o8["status"] == 0) | (o8["status"] == 1)
-        assert ok.sum() + ok8.sum() >= 0.8 * len(ok)
-    assert ok.mean() > 0.5
+        assert ok.sum() + ok8.sum() >= 0.96 * len(ok)
+    assert ok.mean() > 0.93                          # 30 of 32: measured at 8192 unique seeds 99.6 % (restart phase)
     x, u = o6["xopt"][ok], o6["uopt"][ok]
     assert dynamics_residual(x, u, b["Ts"][ok]).max() < 1e-7
     assert np.abs(u[:, 0]).max() <= 0.6 + 1e-7

@@ -96,7 +96,7 @@ def test_c2_batch_is_certified_instance_by_instance():
     b = sc.make_batch(B, N)
     r = _solve(b, N)
     ok = (r["st"] == 0) | (r["st"] == 1)
-    assert ok.mean() > 0.99
+    assert ok.mean() > 0.995
     worst = dict(stationarity=0.0, primal=0.0, dual_sign=0.0, complementarity=0.0)
     for i in np.flatnonzero(ok):
         c = _assert_certified(kkt_check.problem_of(b, i, N), r["z"][i], r["y"][i], r["x"][i], r["u"][i], ("c2", i))
@@ -114,7 +114,7 @@ def test_c3_instances_are_certified_at_N20(gated):
     b = sc.make_batch_c3(B, N, gated=gated)
     r = _solve(b, N)
     ok = (r["st"] == 0) | (r["st"] == 1)
-    assert ok.sum() >= (14 if gated else 22)
+    assert ok.sum() >= (22 if gated else 23)                      # measured at 8192 unique seeds: 99.6 % / 100 %
     for i in np.flatnonzero(ok):
         _assert_certified(kkt_check.problem_of(b, i, N), r["z"][i], r["y"][i], r["x"][i], r["u"][i], ("c3", gated, i))
     cl = kkt_check.min_clearance_boxes(r["x"][ok], (1.7, .75, 1.7, .75), b["m"], b["A"][ok], b["b"][ok])
@@ -143,7 +143,7 @@ def test_c2_full_size_clearance():
     b = sc.make_batch(B, N)
     r = _solve(b, N, cert=False)
     ok = (r["st"] == 0) | (r["st"] == 1)
-    assert ok.mean() > 0.99
+    assert ok.mean() > 0.999                                        # measured: 8192 of 8192
     cl = kkt_check.min_clearance_boxes(r["x"][ok], sc.EGO, b["m"], b["A"][ok], b["b"][ok])
     assert cl.min() >= sc.DMIN - 1e-6, cl.min()
 
@@ -158,7 +158,7 @@ def test_c3_full_size_clearance_on_unique_seeds(gated):
     assert len(np.unique(b["x0"], axis=0)) == B
     r = _solve(b, N, cert=False)
     ok = (r["st"] == 0) | (r["st"] == 1)
-    assert ok.mean() > (0.75 if gated else 0.95)
+    assert ok.mean() > (0.965 if gated else 0.995)                 # measured: 99.56 % / 100 % (within 3 points)
     x, u, ts = r["x"][ok], r["u"][ok], r["ts"][ok]
     cl = kkt_check.min_clearance_boxes(x, sc.EGO, b["m"], b["A"][ok], b["b"][ok])
     assert cl.min() >= sc.DMIN - 1e-6, cl.min()

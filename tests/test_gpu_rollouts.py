@@ -87,7 +87,7 @@ def test_closed_loop_batch_properties():
     steps, flags = o["steps"], o["flags"]
     assert np.all(flags != 0)                                       # every rollout ended: goal, cap or failure
     assert np.all(steps[flags == 2] == 30)
-    assert (flags != 3).mean() > 0.5
+    assert (flags != 3).mean() > 0.88                               # measured: 91 % here, 90.9 % of 4096 (bench.py closed_loop)
     done = 0
     for i in range(B):
         k = steps[i]
@@ -101,7 +101,7 @@ def test_closed_loop_batch_properties():
         assert np.all(o["variant"][i, k + 1:] == 0)
         assert np.all(np.abs(u[:k, 0]) <= 0.6 + 1e-6) and np.all(np.abs(u[:k, 1]) <= np.pi / 6 + 1e-6)
         assert np.all((x[:k + 1, 1] > 1.0) & (x[:k + 1, 1] < 9.0))
-    assert done > 0.6 * 30 * B
+    assert done > 0.93 * 30 * B
     # a second run from reset reproduces the first bit for bit
     dr.reset()
     dr.run()

@@ -12,7 +12,9 @@ nd = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 t = time.time(); w = pack_worlds([make_world_c5(i, n_dyn=nd) for i in range(B)]); print("gen+pack %.1fs" % (time.time() - t))
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import RolloutCohorts
 C = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-dr = RolloutCohorts(w, cohorts=C, N=5)
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
+prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), restart=int(os.environ.get("OBCA_RESTART", "0")))
+dr = RolloutCohorts(w, cohorts=C, N=5, params=prm)
 if len(sys.argv) > 4:
     for p_ in dr.parts: p_.set_mode(sys.argv[4])
 dr.run(2); dr.read(); torch.cuda.synchronize(); dr.reset(); torch.cuda.synchronize()

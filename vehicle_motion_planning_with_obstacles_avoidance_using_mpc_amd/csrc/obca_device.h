@@ -46,6 +46,8 @@
    box, free-time problem: the time scale at which the window is driven at this fraction of the speed bound -- with a
    larger initial barrier parameter (IPOPT's restoration phase likewise raises mu to max(mu, ||c||_inf)). */
 #define OBCA_RESTART_MU 1.0
+#define OBCA_RESTART_MAX_ITER 300    /* iteration limit of the restart pass: the restarts that succeed take 16-117 iterations (C3 gated,
+                                        C5; tools/restart_study.py), one that does not would otherwise run to max_iter = 3000 */
 #define OBCA_WINDOW_SPEED_FRAC 0.9
 
 /* Line-search filter capacity: a function of the problem SHAPE only, so that every kernel that can run a shape (and the
