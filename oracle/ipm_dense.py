@@ -122,6 +122,11 @@ def split_rows(p):
 RHO_ESCALATION = 100.0
 RESTART_MU = 1.0               # barrier parameter a restart begins with (csrc/obca_device.h: OBCA_RESTART_MU)
 RESTART_MAX_ITER = 300         # iteration limit of the restart pass (OBCA_RESTART_MAX_ITER: successful restarts take 16-117)
+
+
+def patience(N):
+    """iteration limit of the passes before the restart, while the restart phase is on (csrc/obca_device.h: OBCA_PATIENCE)"""
+    return 500 + 10 * N
 WINDOW_SPEED_FRAC = 0.9
 
 
@@ -165,6 +170,8 @@ def solve(p, opts=None, trace=None):
       inputs describe -- with a ten times larger barrier parameter (IPOPT raises mu to max(mu, ||c||_inf) when it enters
       restoration) converges on 97 % of them.  A genuinely infeasible problem stays infeasible."""
     opts = dict(opts or {})
+    if not opts.get("no_restart"):
+        opts["max_iter"] = min(opts.get("max_iter", options_for(p.variant)["max_iter"]), patience(p.N))
     r = _solve_once(p, opts, trace)
     rho0 = opts.get("rho", DEFAULTS["rho"])
     if r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation"):

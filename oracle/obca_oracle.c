@@ -351,13 +351,14 @@ static void bk_solve(const double* A, int n, const int* piv, double* b) {
 /* ------------------------------------------------------------------------------------------------------ */
 typedef struct {
     double tol, rho, feas_tol;
-    int max_iter_free, max_iter_fixed, max_soc;
+    int max_iter_free, max_iter_fixed, max_soc, restart;
 } Opts;
 
 #define MU_INIT 0.1
 #define RESTART_MU 1.0            /* csrc/obca_device.h: OBCA_RESTART_MU */
 #define WINDOW_SPEED_FRAC 0.9
 #define RESTART_MAX_ITER 300      /* csrc/obca_device.h: OBCA_RESTART_MAX_ITER */
+#define PATIENCE(N) (500 + 10 * (N)) /* csrc/obca_device.h: OBCA_PATIENCE */
 #define KAPPA_MU 0.2
 #define THETA_MU 1.5
 #define KAPPA_EPS 10.0
@@ -465,7 +466,8 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
         double theta_max = 0, theta_min = 0, dw_last = 0, tau = fmax(TAU_MIN, 1 - mu), fprev = 0;
         int have_prev = 0, acc = 0;
         const int max_iter_v = p->freeT ? o->max_iter_free : o->max_iter_fixed;
-        const int max_iter = (from_window && max_iter_v > RESTART_MAX_ITER) ? RESTART_MAX_ITER : max_iter_v;
+        const int max_iter_w = from_window ? RESTART_MAX_ITER : (o->restart ? PATIENCE(N) : max_iter_v);
+        const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
         const double acc_tol = p->freeT ? 1e-6 : 1e-8, acc_obj = p->freeT ? 1e20 : 1e-6;
         for (it = 0; it <= max_iter; ++it) {
             memset(Je, 0, sizeof(double) * (size_t)me * n);
@@ -841,6 +843,7 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         o.tol = prm->tol > 0 ? prm->tol : 1e-8; o.rho = prm->rho > 0 ? prm->rho : 1e4; o.feas_tol = prm->feas_tol > 0 ? prm->feas_tol : 1e-6;
         o.max_iter_free = prm->max_iter_free > 0 ? prm->max_iter_free : 3000; o.max_iter_fixed = prm->max_iter_fixed > 0 ? prm->max_iter_fixed : 1000;
         o.max_soc = prm->max_soc == 0 ? 4 : (prm->max_soc < 0 ? 0 : prm->max_soc);
+        o.restart = prm->restart >= 0;
         status[q] = solve_one(&p, &o, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, 0, MU_INIT);
         if (status[q] == ST_INFEASIBLE && p.variant == 4) {
             /* one penalty escalation for the free-time problem (see oracle/ipm_dense.py:solve): cold start again, rho x 100 */

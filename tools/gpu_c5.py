@@ -28,3 +28,10 @@ ok = int(o["steps"].sum()); solved = int((o["variant"] > 0).sum())
 print("B=%d n_dyn=%d wall %.2fs converged steps %d (solved %d) -> %.0f steps/s; flags %s; variants %s; mean iters %.1f" % (
     B, nd, dt, ok, solved, ok / dt, np.bincount(o["flags"], minlength=4).tolist(),
     {v: int((o["variant"] == v).sum()) for v in (4, 6, 8)}, o["iters"][o["variant"] > 0].mean()))
+it = o["iters"].astype(float)
+cost = it.sum(1)
+print("iterations: total %.0f, per rollout mean %.0f max %.0f; largest single steps %s; rollouts with > 5000: %d" %
+      (it.sum(), cost.mean(), cost.max(), np.sort(it.ravel())[-8:].astype(int).tolist(), int((cost > 5000).sum())))
+worst = np.argsort(-cost)[:5]
+for b_ in worst:
+    print("  rollout %d: steps %d flag %d cost %.0f iters %s variants %s" % (b_, o["steps"][b_], o["flags"][b_], cost[b_], it[b_].astype(int).tolist(), o["variant"][b_].tolist()))

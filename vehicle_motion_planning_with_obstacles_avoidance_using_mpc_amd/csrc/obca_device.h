@@ -46,6 +46,11 @@
    box, free-time problem: the time scale at which the window is driven at this fraction of the speed bound -- with a
    larger initial barrier parameter (IPOPT's restoration phase likewise raises mu to max(mu, ||c||_inf)). */
 #define OBCA_RESTART_MU 1.0
+/* Patience of the passes BEFORE the restart (only while the restart phase is on): a pass that has not converged after this many
+   iterations is abandoned for the restart.  Measured (tools/restart_study.py): solves either converge well below
+   it -- N = 5: <= 301 iterations, N = 20: <= 389, N = 74: ~500 per pass -- or crawl at an indefinite point with delta_w ~ 1e3
+   until max_iter (3000 for obca_mpc4: 0.27 s on one wavefront), nothing in between. */
+#define OBCA_PATIENCE(N) (500 + 10 * (N))
 #define OBCA_RESTART_MAX_ITER 300    /* iteration limit of the restart pass: the restarts that succeed take 16-117 iterations (C3 gated,
                                         C5; tools/restart_study.py), one that does not would otherwise run to max_iter = 3000 */
 #define OBCA_WINDOW_SPEED_FRAC 0.9

@@ -1730,7 +1730,8 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     ObcaOptsDev O;
     O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho * rho_mult; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed; O.max_soc = Ain.prm.opt.max_soc;          // by value: A may live in HBM (fused closed-loop kernel)
     const int max_iter_v = L.free_T ? O.max_iter_free : O.max_iter_fixed;
-    const int max_iter = (from_window && max_iter_v > OBCA_RESTART_MAX_ITER) ? OBCA_RESTART_MAX_ITER : max_iter_v;
+    const int max_iter_w = from_window ? OBCA_RESTART_MAX_ITER : (Ain.prm.opt.restart ? OBCA_PATIENCE(L.N) : max_iter_v);
+    const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
 
