@@ -29,19 +29,35 @@ ALG_BYTES = {(5, 6): 1320, (5, 12): 2184, (6, 6): 1528}       # SURVEY.md 8(d): 
 HBM_PEAK_GBPS = 8000.0                                          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9        # lanes the VALUs of the chip issue per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12
+
+
+def kernel_source_hash():
+    """hash of the HIP sources the solver kernels are compiled from: the counter passes under profiles/ carry the hash of the
+    sources they measured, so that figures of an OLDER kernel are not reported as current (tools/pmc_summary.py writes it)"""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd", "csrc")
+    for name in ("obca_kernel.hip", "obca_device.h", "obca_rollout_core.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
 
 
 def pmc_summary(kernel, B, N, M):
     """HBM traffic and issue counters of the dominant kernel, from the rocprofv3 --pmc passes committed under profiles/
-    (tools/pmc_summary.py turns the counter CSVs into this file).  None when no pass matches this workload."""
+    (tools/pmc_summary.py turns the counter CSVs into this file).  None when no pass matches this workload; a pass taken on
+    other kernel sources than the ones in the tree is returned with `stale` set and its figures are not reported."""
     try:
         with open(PMC_SUMMARY) as f:
-            rows = json.load(f)["kernels"]
+            doc = json.load(f)
     except Exception:
         return None
-    for r in rows:
+    for r in doc["kernels"]:
         if r.get("kernel") == kernel and (r.get("B"), r.get("N"), r.get("M")) == (B, N, M):
+            r = dict(r, source_hash=doc.get("kernel_source_hash"), git_sha=doc.get("git_sha"))
+            r["stale"] = r["source_hash"] != kernel_source_hash()
             return r
     return None
 
@@ -68,48 +84,50 @@ def alg_bytes(N, M):
     return 8 * (3 + 2 + 3 * (N + 1) + 3 * M * (N + 1) + 1 + 3) + 8 * (3 * (N + 1) + 2 * N + 1) + 8
 
 
-def cpu_baseline(batch, N, seconds=20.0):
-    """Oracle (CPU restatement) timed on the host cores of this box on a bounded sample of the same workload."""
-    try:
-        from oracle import c_oracle
-        have_c = c_oracle.available()
-    except Exception:
-        have_c = False
+def cpu_oracle(batch, N, seconds=10.0):
+    """The dense oracle (plain-C restatement, oracle/obca_oracle.c: dense Bunch-Kaufman KKT solves) timed on the host cores of
+    this box on a bounded sample of the same workload -- context: it is the CHECKER's speed, not a same-algorithm baseline."""
+    from oracle import c_oracle
     cores = os.cpu_count() or 1
-    if have_c:
-        from oracle import c_oracle
-        n, t_used, solved = 0, 0.0, 0
-        chunk = max(cores, 8)
-        t0 = time.time()
-        while time.time() - t0 < seconds and n + chunk <= batch["x0"].shape[0]:
-            sl = slice(n, n + chunk)
-            st = c_oracle.solve_batch(4, N, batch["m"], batch["x0"][sl], batch["u0"][sl], batch["xref"][sl],
-                                      batch["A"][sl], batch["b"][sl], batch["Ts"][sl], None, threads=cores)["status"]
-            solved += int(np.sum((st == 0) | (st == 1)))
-            n += chunk
-        dt = time.time() - t0
-        return {"value": n / dt, "unit": "MPC steps/s", "cores": cores, "kind": "port",
-                "sample": "%d instances of the same batch, C restatement (oracle/obca_oracle.c), %d threads, %.1f s"
-                          % (n, cores, dt), "solved": solved}
-    from oracle import ipm_dense
-    from oracle.obca_nlp import Problem
-    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
-    n = 0
+    n, solved = 0, 0
+    chunk = max(cores, 8)
     t0 = time.time()
-    while time.time() - t0 < seconds and n < batch["x0"].shape[0]:
-        p = Problem(4, N, batch["m"], batch["x0"][n], batch["u0"][n], batch["xref"][n], batch["A"][n], batch["b"][n],
-                    sc.TS, 0.1 * np.eye(3), 0.01 * np.eye(2), 0.1 * np.eye(2), 0.1 * np.eye(3), sc.XL, sc.XU,
-                    [-0.6, -np.pi / 6], [0.6, np.pi / 6], sc.EGO, sc.DMIN)
-        ipm_dense.solve(p)
-        n += 1
+    while time.time() - t0 < seconds and n + chunk <= batch["x0"].shape[0]:
+        sl = slice(n, n + chunk)
+        st = c_oracle.solve_batch(4, N, batch["m"], batch["x0"][sl], batch["u0"][sl], batch["xref"][sl],
+                                  batch["A"][sl], batch["b"][sl], batch["Ts"][sl], None, threads=cores)["status"]
+        solved += int(np.sum((st == 0) | (st == 1)))
+        n += chunk
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "MPC steps/s", "cores": 1, "kind": "port",
-            "sample": "%d instances of the same batch, numpy dense restatement (oracle/ipm_dense.py), %.1f s" % (n, dt)}
+    return {"value": n / dt, "unit": "MPC steps/s", "cores": cores, "solved": solved,
+            "sample": "%d instances of the same batch, dense C oracle (oracle/obca_oracle.c), %d threads, %.1f s" % (n, cores, dt)}
 
 
-def cpu_structured(batch, N):
-    """Context, not the oracle: the GPU kernels' own structured algorithm (csrc/obca_lpi_core.h, the portable core of
-    the lane kernel) compiled for the host and run with OpenMP over instances on all cores (tests/native)."""
+def independent_leg(solver, batch, dv, N, prm, n=64):
+    """An independent solver (SciPy SLSQP on the reference-pinned model, tests/independent.py) on the first n answers of the
+    batch: (a) started at the GPU's answer it must not find a better feasible point; (b) started from the reference window
+    and two perturbations of it -- share of starts that end at the same optimum / another / a better one / nowhere."""
+    from tests import independent as ind, kkt_check
+    solver.enable_certificates()
+    out = solver.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], prm)
+    torch.cuda.synchronize()
+    st = out.status[:n].cpu().numpy()
+    z, y = solver.cert_z[:n].cpu().numpy(), solver.cert_y[:n].cpu().numpy()
+    ok = [i for i in range(n) if st[i] in (0, 1)]
+    ps = {i: kkt_check.problem_of(batch, i, N) for i in ok}
+    procs = max(1, min(128, os.cpu_count() or 1))
+    t0 = time.time()
+    pol = ind.pool_map(ind.polish, [(ps[i], z[i], y[i]) for i in ok], procs)
+    sta = ind.pool_map(ind.from_starts, [(ps[i], z[i], i) for i in ok], procs)
+    res = ind.summarise(pol, sta)
+    res["sample"] = "first %d instances of the batch, SciPy SLSQP on oracle/obca_nlp.py, %d processes, %.1f s" % (n, procs, time.time() - t0)
+    return res
+
+
+def cpu_baseline(batch, N):
+    """The CPU baseline: the same algorithm as the GPU kernels -- the structured core csrc/obca_lpi_core.h (the header the lane
+    kernel compiles), built for the host by tests/native and run with OpenMP over instances on ALL host cores.  (The
+    reference's own solver, CasADi/IPOPT, does not exist in this image: see `ipopt`.)"""
     try:
         from tests import native_build
         native_build.load()
@@ -125,8 +143,8 @@ def cpu_structured(batch, N):
                                 batch["b"][sl], batch["Ts"][sl])["status"]
     solved = int(np.sum((st == 0) | (st == 1)))
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "MPC steps/s", "cores": cores, "solved": solved,
-            "sample": "%d instances of the same batch, structured core on the host, %d OpenMP threads, %.1f s" % (n, cores, dt)}
+    return {"value": n / dt, "unit": "MPC steps/s", "cores": cores, "kind": "port", "solved": solved,
+            "sample": "%d instances of the same batch, structured core (csrc/obca_lpi_core.h) on the host, %d OpenMP threads, %.1f s" % (n, cores, dt)}
 
 
 def config_c3(B, N=20):
@@ -160,7 +178,7 @@ def config_c3(B, N=20):
     return res
 
 
-def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None):
+def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop per GPU, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds first .. first+B-1, resident in HBM
     before the clock starts.  With a process group every rank runs the whole loop for its own worlds (no collective on
@@ -203,6 +221,23 @@ def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None):
     if world == 1:
         res["solves_by_variant"] = {str(v): int((o["variant"] == v).sum()) for v in (4, 6, 8)}
         res["mean_ipm_iters"] = float(o["iters"][o["variant"] > 0].mean())
+        if classify and fails:
+            # genuine / solver split of the rollouts that stopped (reference: `break`, src/closed_loop.py:401-413): every one of
+            # them replayed on the host and its last solve handed to an independent solver (tests/independent.py)
+            try:
+                from tests import independent as ind
+                stopped = np.flatnonzero(o["flags"] == 3)
+                t1 = time.time()
+                rows = ind.pool_map(ind.classify_stopped_world, [(first + int(i), n_dyn, int(o["steps"][i])) for i in stopped],
+                                    max(1, min(192, os.cpu_count() or 1)))
+                same = [r for r in rows if not r["replay_differs"]]
+                res["stopped_infeasible_split"] = {
+                    "classified": len(same), "feasible_point_exists_solver_failure": int(sum(r["feasible_point_found"] for r in same)),
+                    "no_feasible_point_found": int(sum(not r["feasible_point_found"] for r in same)),
+                    "host_replay_stops_elsewhere": len(rows) - len(same),
+                    "method": "host replay of each stopped rollout (structured core), last solve to SciPy SLSQP from three starts on the pinned model, %.1f s" % (time.time() - t1)}
+            except Exception as e:          # noqa: BLE001
+                res["stopped_infeasible_split"] = {"error": repr(e)}
     return res
 
 
@@ -313,7 +348,7 @@ def main():
     total = B * world
     # the closed loop (config C5) sharded the same way: every rank runs the whole loop for its own rollouts
     c5_multi = None
-    if world > 1 and args.closed_loop_rollouts > 0:
+    if dist is not None and args.closed_loop_rollouts > 0:
         try:
             c5_multi = closed_loop_c5(args.closed_loop_rollouts, first=rank * args.closed_loop_rollouts, dist=dist)
         except Exception as e:          # noqa: BLE001
@@ -325,6 +360,7 @@ def main():
         achieved = ab * B / (kern_ms * 1e-3) / 1e9
         kname = "obca_ipm_kernel_r4" if solver_rows <= 256 else "obca_ipm_kernel_r5" if solver_rows <= 320 else "obca_ipm_kernel_r6"
         pmc = pmc_summary(kname, B, N, M)
+        live = pmc if (pmc and not pmc["stale"]) else {}
         line = {
             "metric": "OBCA MPC steps/sec (batch) at N=5, 3 obs", "value": value, "unit": "MPC steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -340,13 +376,20 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS,
                          # HBM bytes per launch measured by the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE x 2,
                          # the gfx950 correction of the microarchitecture guide, + WRITE_SIZE); null when no pass matches
-                         "traffic": (pmc or {}).get("traffic_bytes"), "traffic_source": (pmc or {}).get("source"),
-                         "valu_busy_frac": (pmc or {}).get("valu_busy_frac"), "wave_wait_frac": (pmc or {}).get("wave_wait_frac"),
+                         "traffic": live.get("traffic_bytes"), "traffic_source": live.get("source"),
+                         "traffic_kernel_source_hash": (pmc or {}).get("source_hash"), "traffic_git_sha": (pmc or {}).get("git_sha"),
+                         "traffic_note": None if pmc is None else ("counter passes taken on OTHER kernel sources (hash %s, tree %s): not reported" % (pmc.get("source_hash"), kernel_source_hash()) if pmc["stale"] else "counter passes taken on the kernel sources in the tree"),
+                         "valu_busy_frac": live.get("valu_busy_frac"), "wave_wait_frac": live.get("wave_wait_frac"),
+                         # the bound that binds: VALU instructions issued x 64 lanes over what the chip's VALUs can issue in the
+                         # launch time (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz; an fp64 instruction occupies its SIMD 4 cycles per wave)
+                         "valu_issue_frac": (live["valu_insts"] * 64 / (live["launch_ms"] * 1e-3 * VALU_LANE_RATE)) if live.get("valu_insts") else None,
                          "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_instance": ab,
                          "fp64_model_frac": value / world * (nf_sum / total) * (N + 1) * (32 ** 3 / 3 + 2 * 32 ** 2) / 78.6e12
                          if M == 6 else None,
-                         "note": "latency/fp64-VALU bound by design (SURVEY 8d): ~1.3 KB of HBM traffic per solve; "
-                                 "fp64_model_frac = steps/s x KKT factorisations x (N+1)(s^3/3+2s^2), s=32, over 78.6 TF"},
+                         "note": "latency/fp64-VALU-issue bound by design (SURVEY 8d): ~1.3 KB of HBM traffic per solve, so the HBM "
+                                 "fraction is ~3e-5 by construction; valu_issue_frac is the figure that describes the kernel.  "
+                                 "fp64_model_frac = steps/s x KKT factorisations x (N+1)(s^3/3+2s^2), s=32, over 78.6 TF counts dense-block "
+                                 "model flops the structured solve never executes -- a SURVEY 8d convention, not an achieved rate"},
         }
         if world == 8 and B == 8192:
             line["config"]["workload"] += " -- this is config C4 (65 536 scenarios sharded over 8 GPUs, gather only)"
@@ -354,22 +397,29 @@ def main():
             line["closed_loop"] = c5_multi
         if small is not None:
             line["batch_1024"] = small
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(batch, N, args.cpu_seconds)
+        if dist is None and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(batch, N)
+            except Exception as e:              # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+            try:
+                line["cpu_oracle"] = cpu_oracle(batch, N, min(args.cpu_seconds, 10.0))
+            except Exception as e:              # noqa: BLE001
+                line["cpu_oracle"] = {"value": None, "error": repr(e)}
             try:                                # the reference's own solver, where it exists (it does not in this image)
                 line["ipopt"] = ipopt_leg(batch, N)
             except Exception as e:              # noqa: BLE001
                 line["ipopt"] = {"error": repr(e)}
             if line["ipopt"] == "unavailable":
-                line["cpu_baseline"]["note"] = "IPOPT unavailable (`import casadi` fails on this box): the CPU figure is the build's own C restatement of the same interior-point method; the reference publishes 3.7 s per solve at N=10 (src/simulation.py:231)"
-            try:
-                line["cpu_structured_core"] = cpu_structured(batch, N)
-            except Exception as e:              # noqa: BLE001  (context figure only)
-                line["cpu_structured_core"] = {"value": None, "error": repr(e)}
-        if world == 1 and args.closed_loop_rollouts > 0:
+                line["cpu_baseline"]["note"] = "IPOPT unavailable (`import casadi` fails on this box); the reference publishes 3.7 s per solve at N=10 (src/simulation.py:231)"
+            try:                                # an independent solver on the pinned model instead (tests/independent.py)
+                line["independent_solver"] = independent_leg(solver, batch, dv, N, prm)
+            except Exception as e:              # noqa: BLE001
+                line["independent_solver"] = {"error": repr(e)}
+        if dist is None and args.closed_loop_rollouts > 0:
             # secondary figures: a failure in one of them must not cost the headline line
             extras = (("config_c3", lambda: config_c3(B)),
-                      ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts)),
+                      ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts, classify=not args.no_cpu_baseline)),
                       # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes
                       ("closed_loop_static", lambda: closed_loop_c5(B, n_dyn=0)),
                       # optional extension, NOT reference behaviour (the reference cold-starts): shifted previous plan

@@ -241,8 +241,16 @@ int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
  * Mode 1 forces the lock-step launches. */
 int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_stream);
 int obca_rollouts_set_mode(obca_rollouts* r, int mode);
-/* Diagnostic (-DOBCA_RO_STATS builds): per persistent workgroup [wait, work (10 ns units), items, end clock], n ints to host */
+/* Diagnostic (-DOBCA_RO_STATS builds): per persistent workgroup [wait, work (10 ns units), items, end clock], n <= 16384 ints to host */
 int obca_rollouts_debug_stats(obca_rollouts* r, int32_t* out, int n);
+/* Test hook: runs ONLY the harness part of a step (obstacle advance, lidar gate, reference window, fixed-time preparation,
+ * half-space rows of the moving rectangles -- everything before the solve) for every rollout, after setting its step counter
+ * to k, its inherited step length to Ts_opt and (x0_host != NULL) its pose to x0_host[3]; then copies what the harness handed
+ * the solver of group g (= number of sensed moving obstacles) to HOST buffers: variant [B] (0: the rollout is not in this
+ * group), A [B,N_g+1,M_g,2], b [B,N_g+1,M_g] with M_g = static rows + 4 g, N_g = N (g = 0) or N_fix.  Synchronises.  The
+ * rollout state is left as the harness left it (moving obstacles advanced): obca_rollouts_reset before running on. */
+int obca_rollouts_debug_harness(obca_rollouts* r, int32_t k, double Ts_opt, const double* x0_host, int32_t g,
+                                int32_t* variant, double* A, double* b, void* hip_stream);
 
 /* Optional, NOT reference behaviour (see obca_set_warm_start): a step whose problem shape equals the previous step's
  * starts from the previous plan moved one stage forward with barrier parameter mu_init.  Call before

@@ -1,6 +1,6 @@
 """Launches the kernels the profiles/ passes look at, and nothing else: `c2` = obca_ipm_kernel_r4 at B = 8192 (headline),
 `c5` = obca_rollout_fused_kernel_r5 (4096 rollouts, two moving boxes), `c3g` = obca_ipm_kernel_mw_r5 (N = 20, gated).
-Run under `rocprofv3 --kernel-trace --stats` or one `--pmc` pass at a time (tools/profile_r02.sh)."""
+Run under `rocprofv3 --kernel-trace --stats` or one `--pmc` pass at a time (tools/profile.sh)."""
 import sys
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -10,14 +10,13 @@ from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver impor
 what = sys.argv[1] if len(sys.argv) > 1 else "c2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 mode = None
-if what in ("c2", "c2w2"):
+if what == "c2":
     B, N = 8192, 5
     b = sc.make_batch(B, N)
-    mode = "twowave" if what == "c2w2" else None
 elif what == "c3g":
     B, N = 2048, 20
     b = sc.make_batch_c3(B, N, gated=True, procs=16)
-if what in ("c2", "c2w2", "c3g"):
+if what in ("c2", "c3g"):
     s = BatchSolver(N, b["m"], max_batch=B, mode=mode)
     dv = {k: torch.as_tensor(b[k], device="cuda") for k in ("variant", "x0", "u0", "xref", "A", "b", "Ts", "term")}
     out = None

@@ -1,4 +1,4 @@
-"""Condenses the rocprofv3 outputs of tools/profile_r02.sh (gpurun_out/prof_<tag>/) into the files committed under profiles/:
+"""Condenses the rocprofv3 outputs of tools/profile.sh (gpurun_out/prof_<tag>/) into the files committed under profiles/:
 per-kernel launch durations from the kernel trace, the --stats table, FETCH_SIZE / WRITE_SIZE per launch (KiB as rocprofv3
 reports them; FETCH_SIZE doubled for HBM bytes as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950) and the SQ
 issue counters, plus profiles/<tag>_pmc_summary.json, which bench.py reads for `roofline.traffic`."""
@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 SHAPES = {"c2": dict(B=8192, N=5, M=6), "c5": dict(B=4096, N=5, M=14), "c3g": dict(B=2048, N=20, M=14)}
@@ -26,7 +26,14 @@ def find(d, pattern):
     return hits[0] if hits else None
 
 
-out = {"tag": tag, "kernels": []}
+sys.path.insert(0, ROOT)
+import subprocess  # noqa: E402
+import bench  # noqa: E402  (kernel_source_hash: the sources these passes measured -- run this right after the profile run)
+try:
+    sha = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+except Exception:
+    sha = None
+out = {"tag": tag, "kernel_source_hash": bench.kernel_source_hash(), "git_sha": sha, "kernels": []}
 # stats + per-launch durations of the bench run
 st = find(os.path.join(src, "trace"), "*kernel_stats.csv")
 if st:
@@ -78,7 +85,7 @@ for tgt, shape in SHAPES.items():
             g = lambda n: max(e[n]) if n in e else None
             rec.update(sq_wave_cycles=wc, valu_busy_frac=g("SQ_ACTIVE_INST_VALU") / wc, wave_wait_frac=g("SQ_WAIT_ANY") / wc,
                        inst_any_frac=g("SQ_ACTIVE_INST_ANY") / wc, issue_stall_frac=(g("SQ_WAIT_INST_ANY") or 0) / wc,
-                       valu_insts_per_wave=g("SQ_INSTS_VALU") / max(g("SQ_WAVES") or 1, 1))
+                       valu_insts_per_wave=g("SQ_INSTS_VALU") / max(g("SQ_WAVES") or 1, 1), valu_insts=g("SQ_INSTS_VALU"))
         out["kernels"].append(rec)
 with open(os.path.join(dst, tag + "_pmc_summary.json"), "w") as f:
     json.dump(out, f, indent=1)

@@ -40,7 +40,7 @@ class ObcaRolloutDims(ctypes.Structure):
 
 
 EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",
-           "obca_set_profile_buffer", "obca_set_mode", "obca_set_two_sided_sweep", "obca_rollouts_create", "obca_rollouts_destroy", "obca_rollouts_debug_stats",
+           "obca_set_profile_buffer", "obca_set_mode", "obca_set_two_sided_sweep", "obca_rollouts_create", "obca_rollouts_destroy", "obca_rollouts_debug_stats", "obca_rollouts_debug_harness",
            "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read", "obca_rollouts_run",
            "obca_rollouts_set_mode", "obca_astar_batch", "obca_astar_workspace_bytes", "obca_primal_size", "obca_set_warm_start",
            "obca_rollouts_set_warm_start", "obca_dual_size", "obca_set_certificate_buffers", "obca_rasterise_batch")
@@ -115,6 +115,8 @@ def load():
     lib.obca_rollouts_step.restype = ctypes.c_int
     lib.obca_rollouts_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, vp]
     lib.obca_rollouts_run.restype = ctypes.c_int
+    lib.obca_rollouts_debug_harness.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, vp, ctypes.c_int32, vp, vp, vp, vp]
+    lib.obca_rollouts_debug_harness.restype = ctypes.c_int
     lib.obca_rollouts_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.obca_rollouts_set_mode.restype = ctypes.c_int
     lib.obca_astar_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]

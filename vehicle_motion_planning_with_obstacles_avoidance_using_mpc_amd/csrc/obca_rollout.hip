@@ -51,6 +51,7 @@ struct obca_rollouts {
     int sched_mode;           /* 1: step-granular work queue (default), 0: one workgroup per rollout (OBCA_ROLLOUT_QUEUE=0) */
     ObcaLaunch hL[2 * rollout::MAX_GROUPS];            // [g]: obca_mpc4 (g = 0) / obca_mpc6, [g + MAX_GROUPS]: obca_mpc8 where obca_mpc6 failed
     bool fused_ok;
+    bool queue_ran;           /* the last obca_rollouts_run used the device-side work queue (its abort flag is then checked by read) */
     int32_t rows_max;
     int64_t lds_max;
     int mode;                 /* 0 auto (fused when every shape fits the wave kernel), 1 lock-step launches */
@@ -147,7 +148,7 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
     r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0; r->warm_mu = 0.0;
     if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS))) rc = OBCA_E_NOMEM;
-    r->sched = nullptr; r->n_slots = 1024; r->sched_mode = 1;
+    r->sched = nullptr; r->n_slots = 1024; r->sched_mode = 1; r->queue_ran = false;
     if (rc == OBCA_OK && !dev_alloc(r, r->sched, (size_t)d->batch + 2 + 4 * 4096)) rc = OBCA_E_NOMEM;   // (+ per-workgroup statistics of -DOBCA_RO_STATS builds)
     {
         int cus = 0;
@@ -289,8 +290,40 @@ extern "C" int obca_rollouts_set_warm_start(obca_rollouts* r, int enable, double
 }
 
 extern "C" int obca_rollouts_debug_stats(obca_rollouts* r, int32_t* out, int n) {      // -DOBCA_RO_STATS builds: [n_slots][4] ints to host
-    if (!r || !out) return OBCA_E_INVAL;
+    if (!r || !out || n < 0 || n > 4 * 4096) return OBCA_E_INVAL;
+    ObcaDeviceGuard guard(r->dims.device);
+    if (!guard.ok) return OBCA_E_HIP;
     return hipMemcpy(out, r->sched + 2 + r->D.B, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? OBCA_OK : OBCA_E_HIP;
+}
+
+__global__ void rollout_debug_state_kernel(rollout::Dev D, int k, double Ts_opt, double x, double y, double th, int set_pose) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= D.B) return;
+    D.k[b] = k; D.Ts_opt[b] = Ts_opt; D.flags[b] = OBCA_RUN;
+    if (set_pose) { D.x0[3 * b] = x; D.x0[3 * b + 1] = y; D.x0[3 * b + 2] = th; }
+}
+
+// Test hook: the harness part of a step alone (rows S4, S5, H2-H5 of SURVEY 8a), with step counter, inherited step length
+// and pose given by the caller, and what it hands the solver of group g copied to HOST buffers.
+extern "C" int obca_rollouts_debug_harness(obca_rollouts* r, int32_t k, double Ts_opt, const double* x0_host, int32_t g,
+                                           int32_t* variant, double* A, double* b, void* hip_stream) {
+    if (!r || !r->ready || k < 0 || k >= r->D.S || g < 0 || g > r->D.n_dyn) return OBCA_E_INVAL;
+    ObcaDeviceGuard guard(r->dims.device);
+    if (!guard.ok) return OBCA_E_HIP;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const rollout::Dev& D = r->D;
+    const dim3 grid((D.B + 63) / 64), block(64);
+    hipLaunchKernelGGL(rollout_debug_state_kernel, grid, block, 0, s, D, (int)k, Ts_opt, x0_host ? x0_host[0] : 0.0,
+                       x0_host ? x0_host[1] : 0.0, x0_host ? x0_host[2] : 0.0, x0_host ? 1 : 0);
+    hipLaunchKernelGGL(rollout_prepare_kernel, grid, block, 0, s, D);
+    if (hipGetLastError() != hipSuccess) return OBCA_E_HIP;
+    const size_t B = D.B, N1 = (g == 0 ? D.N : D.Nf) + 1, Mg = D.Ms + 4 * g;
+    auto cp = [&](void* dst, const void* src, size_t bytes) {
+        return !dst || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s) == hipSuccess;
+    };
+    if (!cp(variant, D.var[g], sizeof(int32_t) * B) || !cp(A, D.A[g], sizeof(double) * B * N1 * Mg * 2) ||
+        !cp(b, D.b[g], sizeof(double) * B * N1 * Mg)) return OBCA_E_HIP;
+    return hipStreamSynchronize(s) == hipSuccess ? OBCA_OK : OBCA_E_HIP;
 }
 
 extern "C" int obca_rollouts_set_mode(obca_rollouts* r, int mode) {
@@ -308,6 +341,7 @@ extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_st
         // persistent workgroups taking (round, rollout) items from a counter; one workgroup per rollout when the queue is off
         const bool queue = r->sched_mode != 0 && (long long)n_steps * r->D.B < (1ll << 30);
         int* sched = queue ? r->sched : nullptr;
+        r->queue_ran = queue;
         if (queue && hipMemsetAsync(r->sched, 0, sizeof(int32_t) * ((size_t)r->D.B + 2), (hipStream_t)hip_stream) != hipSuccess) return OBCA_E_HIP;
         const int grid = queue ? (r->D.B < r->n_slots ? r->D.B : r->n_slots) : r->D.B;
         if (r->rows_max <= 256)
@@ -348,8 +382,9 @@ extern "C" int obca_rollouts_read(obca_rollouts* r, double* x_closed, double* u_
     if (!ok) return OBCA_E_HIP;
     // the fused kernel's work queue gives up (instead of hanging the GPU) if a rollout's previous round is never published:
     // that must not pass for a result
+    // (only after a run that used the queue: this is the one place where read synchronises with the stream)
     int32_t aborted = 0;
-    if (r->sched && (hipMemcpyAsync(&aborted, r->sched + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                     hipStreamSynchronize(s) != hipSuccess)) return OBCA_E_HIP;
+    if (r->queue_ran && (hipMemcpyAsync(&aborted, r->sched + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                         hipStreamSynchronize(s) != hipSuccess)) return OBCA_E_HIP;
     return aborted ? OBCA_E_HIP : OBCA_OK;
 }

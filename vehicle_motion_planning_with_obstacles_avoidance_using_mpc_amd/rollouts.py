@@ -232,6 +232,17 @@ class DeviceRollouts:
         _lib.check(self.lib.obca_rollouts_read(self._h, *ptrs, self._stream()))
         return out
 
+    def debug_harness(self, k, Ts_opt, x0=None, g=0):
+        """test hook (obca_rollouts_debug_harness): the harness part of a step alone with step counter, inherited step length
+        and pose given; returns what it handed the solver of group g: (variant [B], A [B,N_g+1,M_g,2], b [B,N_g+1,M_g]) as numpy"""
+        B, Ng = self.w.batch, (self.N if g == 0 else self.N_fix)
+        Mg = self.w.static_A.shape[1] + 4 * g
+        var, A, b = np.zeros(B, np.int32), np.zeros((B, Ng + 1, Mg, 2)), np.zeros((B, Ng + 1, Mg))
+        x0a = None if x0 is None else np.ascontiguousarray(x0, float)
+        p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(self.lib.obca_rollouts_debug_harness(self._h, int(k), float(Ts_opt), p(x0a), int(g), p(var), p(A), p(b), self._stream()))
+        return var, A, b
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.obca_rollouts_destroy(self._h)
