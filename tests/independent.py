@@ -151,7 +151,7 @@ def classify(job):
             z0 = trajectory_start(p, np.linspace(p.x0, end, p.N + 1).T)
         else:
             z0 = np.asarray(z_last, float)[:p.n].copy()
-        r = slsqp(p, z0)
+        r = slsqp(p, z0, maxiter=250)
         cand = dict(start=kind, viol=r["viol"], f=r["f"], nit=r["nit"])
         if best is None or (cand["viol"] <= FEAS_TOL and (best["viol"] > FEAS_TOL or cand["f"] < best["f"])) or \
                 (best["viol"] > FEAS_TOL and cand["viol"] < best["viol"]):

@@ -8,7 +8,20 @@ import ctypes
 import math
 
 import numpy as np
-import torch
+
+
+class _LazyTorch:
+    """torch is imported on first use: the host-side mirror of the reference's loop (closed_loop.py) needs
+    ``pack_reference_call`` from this module, and the worker processes that replay rollouts on the CPU (tests/independent.py)
+    should not pay for -- or depend on -- PyTorch"""
+
+    def __getattr__(self, name):
+        import torch as t
+        globals()["torch"] = t
+        return getattr(t, name)
+
+
+torch = _LazyTorch()
 
 from . import _lib
 
@@ -126,8 +139,8 @@ class BatchSolver:
         except Exception:
             pass
 
-    def _dev(self, t, shape, dtype=torch.float64):
-        t = torch.as_tensor(t, dtype=dtype, device=self.device).contiguous()
+    def _dev(self, t, shape, dtype=None):
+        t = torch.as_tensor(t, dtype=dtype or torch.float64, device=self.device).contiguous()
         if tuple(t.shape) != tuple(shape):
             raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
         return t
