@@ -153,10 +153,12 @@ int obca_set_certificate_buffers(obca_handle* h, double* z, double* y);
 
 /* Kernel selection: 0 = auto (default; also env OBCA_MODE): one wavefront per instance when its rows fit the
  * wavefront's registers (<= 384 rows) and its working set one CU's LDS; else four wavefronts per instance when the
- * working set still fits the LDS (<= 768 rows, e.g. N = 20 with three obstacles); else the lane-per-instance kernel.
+ * working set still fits the LDS (<= 1280 rows, e.g. N = 20 with five obstacles); else four wavefronts per instance with the
+ * row state and every O(rows) array in an HBM workspace owned by the handle and only the O(N) blocks of the stage-serial
+ * Riccati sweep in LDS (long horizons: N = 74 with five obstacles has 3976 rows); else (N > ~150) the lane-per-instance kernel.
  * 1 = one wavefront per instance; 2 = lane-per-instance (64 instances per wavefront, working set in an HBM workspace
- * owned by the handle; any shape, e.g. N = 20 with five obstacles); 3 = four wavefronts per instance.
- * Returns OBCA_E_LDS if mode 1 / 3 cannot hold the shape. */
+ * owned by the handle; any shape); 3 = four wavefronts per instance, LDS resident; 4 = four wavefronts per instance, HBM
+ * workspace.  Returns OBCA_E_LDS if mode 1 / 3 / 4 cannot hold the shape. */
 int obca_set_mode(obca_handle* h, int mode);
 
 /* Four-wavefront kernels (OBCA_MODE 3, and auto mode for shapes whose rows do not fit one wavefront's registers): the

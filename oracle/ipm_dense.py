@@ -121,7 +121,9 @@ def split_rows(p):
 
 RHO_ESCALATION = 100.0
 RESTART_MU = 1.0               # barrier parameter a restart begins with (csrc/obca_device.h: OBCA_RESTART_MU)
-RESTART_MAX_ITER = 300         # iteration limit of the restart pass (OBCA_RESTART_MAX_ITER: successful restarts take 16-117)
+def restart_max_iter(N):
+    """iteration limit of the restart pass (OBCA_RESTART_MAX_ITER: successful restarts take 16-117 iterations at N <= 20)"""
+    return 300 + 10 * N
 
 
 def patience(N):
@@ -179,7 +181,7 @@ def solve(p, opts=None, trace=None):
     if r.status not in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS) and not opts.get("no_restart"):
         esc = p.variant == 4 and r.status == STATUS_INFEASIBLE and not opts.get("no_escalation")
         o3 = dict(opts, rho=rho0 * (RHO_ESCALATION if esc else 1.0), mu_init=RESTART_MU,
-                  max_iter=min(RESTART_MAX_ITER, opts.get("max_iter", options_for(p.variant)["max_iter"])))
+                  max_iter=min(restart_max_iter(p.N), opts.get("max_iter", options_for(p.variant)["max_iter"])))
         r = _accumulate(_solve_once(p, o3, trace, x_start=window_start(p)), r)
         r.restarted = True
     return r

@@ -357,7 +357,7 @@ typedef struct {
 #define MU_INIT 0.1
 #define RESTART_MU 1.0            /* csrc/obca_device.h: OBCA_RESTART_MU */
 #define WINDOW_SPEED_FRAC 0.9
-#define RESTART_MAX_ITER 300      /* csrc/obca_device.h: OBCA_RESTART_MAX_ITER */
+#define RESTART_MAX_ITER(N) (300 + 10 * (N)) /* csrc/obca_device.h: OBCA_RESTART_MAX_ITER */
 #define PATIENCE(N) (500 + 10 * (N)) /* csrc/obca_device.h: OBCA_PATIENCE */
 #define KAPPA_MU 0.2
 #define THETA_MU 1.5
@@ -466,7 +466,7 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
         double theta_max = 0, theta_min = 0, dw_last = 0, tau = fmax(TAU_MIN, 1 - mu), fprev = 0;
         int have_prev = 0, acc = 0;
         const int max_iter_v = p->freeT ? o->max_iter_free : o->max_iter_fixed;
-        const int max_iter_w = from_window ? RESTART_MAX_ITER : (o->restart ? PATIENCE(N) : max_iter_v);
+        const int max_iter_w = from_window ? RESTART_MAX_ITER(N) : (o->restart ? PATIENCE(N) : max_iter_v);
         const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
         const double acc_tol = p->freeT ? 1e-6 : 1e-8, acc_obj = p->freeT ? 1e20 : 1e-6;
         for (it = 0; it <= max_iter; ++it) {

@@ -189,3 +189,43 @@ def test_invalid_variants_are_per_instance_errors():
         assert rc == 0 and outs[3].cpu().tolist() == [_lib.STATUS_BAD_VARIANT, 0, _lib.STATUS_SKIPPED, 0]
         assert float(outs[0][0].abs().max()) == 0.0
         s.close()
+
+
+def test_hbm_workspace_kernel_is_bit_identical_to_the_lds_kernel():
+    """mode "global" (obca_ipm_kernel_gm: four wavefronts per instance, row state and every O(rows) array in an HBM workspace,
+    only the O(N) blocks of the Riccati sweep in LDS -- the kernel auto mode picks beyond the LDS) on shapes the LDS-resident
+    four-wavefront kernel also runs: same code, same thread <-> row assignment, same arithmetic => identical output words"""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+    for b, N in ((sc.make_batch(128, 5), 5), (sc.make_batch_c3(48, 20, gated=False), 20), (sc.make_batch_c3(48, 20, gated=True), 20)):
+        res = []
+        for mode in ("multiwave", "global"):
+            s = BatchSolver(N, b["m"], max_batch=len(b["variant"]), mode=mode)
+            o = s.solve(b["variant"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], SolverParams())
+            torch.cuda.synchronize()
+            res.append((o.xopt.cpu().numpy(), o.uopt.cpu().numpy(), o.ts_opt.cpu().numpy(), o.status.cpu().numpy(), o.iters.cpu().numpy()))
+            s.close()
+        for a, c in zip(*res):
+            assert np.array_equal(a, c)
+
+
+def test_auto_mode_picks_the_hbm_workspace_kernel_beyond_the_lds():
+    """N = 34 with five obstacles (1870 rows, 270 KB of LDS if it were resident): a batch through auto mode and through the
+    lane kernel -- same verdicts, same plans where the iteration counts agree"""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+    N, B = 34, 32
+    b = sc.make_batch_c3(B, N, gated=True)
+    res = {}
+    for mode in (None, "lane"):
+        s = BatchSolver(N, b["m"], max_batch=B, mode=mode)
+        if mode is None:
+            assert s.lds_bytes > 160 * 1024
+        o = s.solve(b["variant"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], SolverParams())
+        torch.cuda.synchronize()
+        res[mode] = (o.xopt.cpu().numpy(), o.status.cpu().numpy(), o.iters.cpu().numpy())
+        s.close()
+    ok_a, ok_l = np.isin(res[None][1], (0, 1)), np.isin(res["lane"][1], (0, 1))
+    assert ok_a.mean() > 0.9 and (ok_a != ok_l).sum() <= 2
+    same = ok_a & ok_l & (res[None][2] == res["lane"][2])
+    assert same.sum() >= 0.3 * B and np.abs(res[None][0] - res["lane"][0])[same].max() < 1e-7

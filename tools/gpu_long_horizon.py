@@ -1,0 +1,22 @@
+"""dev tool: the reference's long-horizon open-loop plans (src/simulation.py:225-231) on the GPU: status, iterations, time"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '.')
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
+cases = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]] or [("demo1", 74), ("demo9", 74)]
+for demo, N in cases:
+    s = obca()
+    import os
+    if os.environ.get('NO_RESTART'): s.restart_all = False
+    cl = closedLoop(problemSetting(demo), solver=s)
+    cl.N_free = N
+    cl.mpc_openLoop_freeTime()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    cl.mpc_openLoop_freeTime()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    sv = list(s._solvers.values())[0]
+    print("%s N=%d: feas %s Ts_opt %.5f, %.3f s; last status/iters: %s" % (demo, N, cl.feas, cl.Ts_opt, dt, getattr(s, "last", None)), flush=True)

@@ -14,6 +14,7 @@ extern "C" __global__ void obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2, ObcaL
 extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
 extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);          // four wavefronts per instance (obca_kernel_mw.hip)
 extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
+extern "C" __global__ void obca_ipm_kernel_gm(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);             // four wavefronts, rows in an HBM workspace
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
 struct obca_handle {
@@ -22,6 +23,10 @@ struct obca_handle {
     int32_t offm[OBCA_MAX_OBST + 1];
     int two_sided;                     // -1: where only the four-wavefront kernels fit (default), 0: never, 1: always
     int64_t lds_bytes, lds_bytes_mw;   // one-wavefront kernels; four-wavefront kernels (+ the two-sided sweep's storage)
+    int64_t lds_bytes_gm, gm_doubles;  // obca_ipm_kernel_gm: its LDS (O(N) blocks only) and its HBM workspace per workgroup
+    int32_t inst_off_gm;
+    bool gm_ok;
+    double* gm_ws;                     // allocated on first use: max_batch slices
     double* prof;
     int mode;                 /* 0 auto, 1 wave-per-instance (LDS), 2 lane-per-instance (HBM workspace), 3 four waves per instance */
     bool wave_ok;             /* the one-wavefront LDS kernel can hold this shape */
@@ -76,6 +81,36 @@ int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off)
     return t;
 }
 
+// the same for obca_ipm_kernel_gm (GM branch of the carve-up): LDS doubles, offset of the instance block, workspace doubles
+int64_t gm_doubles(int N, int nO, int M, int n_max, int R_max, int& inst_off, int64_t& ws) {
+    const int N1 = N + 1, np = N1 * nO;
+    int64_t t = 0, g = 0;
+    auto take = [&](int64_t c) { t += (c + 1) & ~int64_t(1); };
+    auto takeG = [&](int64_t c) { g += (c + 1) & ~int64_t(1); };
+    takeG(n_max); takeG(n_max > 120 ? n_max : 120); take(5 * N1 + 1); takeG(n_max);
+    for (int i = 0; i < 5; ++i) takeG(R_max);
+    take(3 * N1 + 3);
+    take(N1); take(N1); takeG(2 * np); take(N1); take(N1); takeG(2 * np);
+    takeG(2 * np); takeG(2 * np); takeG(2 * np);
+    takeG(N1 * M * 2); takeG(N1 * M); take(3 * N1);
+    take(36 * N1); take(8 * N1);
+    {
+        const int64_t nx = (n_max + 1) & ~1, nr = (R_max + 1) & ~1, ny = (int64_t)MW * 4 * np;
+        takeG(ny > nx + nr ? ny : nx + nr);
+    }
+    take(36 * N1); takeG(12 * np);
+    take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
+    take(120);               // FG / Mall / mall
+    take(32); take(8);
+    take(3 * N1 + 3); take(3 * N1 + 3); take(2 * N1 + 2);      // mirrors of the soft rows' E^-1, ghat; inputs + time scale
+    const int64_t rs = (int64_t)((R_max + 255) / 256) * 256;
+    for (int i = 0; i < 15; ++i) takeG(rs);                    // row state (OBCA_ROW_FIELDS)
+    inst_off = (int)t;
+    take(OBCA_INST_DOUBLES);
+    ws = g;
+    return t;
+}
+
 }  // namespace
 
 extern "C" int64_t obca_lds_bytes(const obca_dims* d) {
@@ -103,9 +138,18 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     h->lds_bytes_mw = h->lds_bytes + 8 * OBCA_ZK_DOUBLES(d->N);
     h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
     h->mw_ok = !(h->lds_bytes_mw + 64 > 160 * 1024 || h->R_max > 1280); // 256 threads x 3 or 5 rows; 32 B of static LDS
+    h->lds_bytes_gm = 8 * (gm_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off_gm, h->gm_doubles) + OBCA_ZK_DOUBLES(d->N));
+    h->gm_ok = h->lds_bytes_gm + 64 <= 160 * 1024;
+    h->gm_ws = nullptr;
     ObcaDeviceGuard guard(d->device);
     if (!guard.ok) { delete h; return OBCA_E_HIP; }
     // a kernel whose LDS request the runtime refuses is simply not offered (the lane kernel serves every shape)
+    if (h->gm_ok && h->lds_bytes_gm > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(obca_ipm_kernel_gm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h->lds_bytes_gm) != hipSuccess) {
+        (void)hipGetLastError();
+        h->gm_ok = false;
+    }
     if (h->mw_ok && h->lds_bytes_mw > 64 * 1024 &&
         hipFuncSetAttribute(h->R_max <= 768 ? reinterpret_cast<const void*>(obca_ipm_kernel_mw_r3)
                                             : reinterpret_cast<const void*>(obca_ipm_kernel_mw_r5),
@@ -127,7 +171,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     if (const char* e = getenv("OBCA_TWO_SIDED")) { const int v = atoi(e); if (v >= -1 && v <= 1) h->two_sided = v; }
     if (const char* e = getenv("OBCA_MODE")) {
         const int m = atoi(e);                                     // out of range or not available for this shape: auto
-        if (m >= 0 && m <= 3 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok)) h->mode = m;
+        if (m >= 0 && m <= 4 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok) && !(m == 4 && !h->gm_ok)) h->mode = m;
     }
     h->ws = nullptr; h->d_offm = nullptr;
     h->ws_stride = ((size_t)d->max_batch + 63) / 64 * 64;
@@ -136,7 +180,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     h->warm_z = nullptr; h->warm_use = nullptr; h->warm_mu = 0.0;
     h->cert_z = nullptr; h->cert_y = nullptr;
     h->soc_ws = nullptr;
-    if (h->wave_ok || h->mw_ok) {
+    if (h->wave_ok || h->mw_ok || h->gm_ok) {
         const size_t stride = (size_t)h->n_max + 2 * (size_t)h->R_max + 2 * (size_t)(d->N + 1) * d->n_obs;
         if (hipMalloc(&h->soc_ws, sizeof(double) * stride * (size_t)d->max_batch) != hipSuccess) { h->soc_ws = nullptr; delete h; return OBCA_E_NOMEM; }
     }
@@ -148,13 +192,15 @@ extern "C" void obca_destroy(obca_handle* h) {
     if (!h) return;
     ObcaDeviceGuard guard(h->dims.device);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->gm_ws) (void)hipFree(h->gm_ws);
     if (h->soc_ws) (void)hipFree(h->soc_ws);
     if (h->d_offm) (void)hipFree(h->d_offm);
     delete h;
 }
 
 extern "C" int obca_set_mode(obca_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 3) return OBCA_E_INVAL;
+    if (!h || mode < 0 || mode > 4) return OBCA_E_INVAL;
+    if (mode == 4 && !h->gm_ok) return OBCA_E_LDS;
     if (mode == 1 && !h->wave_ok) return OBCA_E_LDS;
     if (mode == 3 && !h->mw_ok) return OBCA_E_LDS;
     h->mode = mode;
@@ -267,6 +313,19 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     // (every access is an L2/HBM round trip at one wave per SIMD) and 4-10x slower where both run
     if (h->mode == 1 && !h->wave_ok) return OBCA_E_LDS;
     if (h->mode == 3 && !h->mw_ok) return OBCA_E_LDS;
+    if (h->mode == 4 || (h->mode == 0 && !h->wave_ok && !h->mw_ok && h->gm_ok)) {
+        // shapes beyond the LDS: four wavefronts per instance, rows and O(rows) arrays in the handle's HBM workspace
+        if (!h->gm_ok) return OBCA_E_LDS;
+        if (!h->gm_ws && hipMalloc(&h->gm_ws, sizeof(double) * (size_t)h->gm_doubles * (size_t)h->dims.max_batch) != hipSuccess) {
+            h->gm_ws = nullptr;
+            return OBCA_E_NOMEM;
+        }
+        L.inst_off = h->inst_off_gm;
+        L.gm_ws = h->gm_ws; L.gm_stride = h->gm_doubles;
+        ObcaLaunch L2 = L;
+        hipLaunchKernelGGL(obca_ipm_kernel_gm, dim3(B), dim3(256), (size_t)h->lds_bytes_gm, (hipStream_t)hip_stream, L, L2, L2);
+        return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
+    }
     // one wavefront per instance where the rows fit its registers; four wavefronts (one CU) per instance for bigger
     // shapes that still fit the LDS; the lane kernel for everything else
     // (the choice depends on the SHAPE only, never on the batch size: the answer to an instance must not depend on how many

@@ -51,8 +51,10 @@
    it -- N = 5: <= 301 iterations, N = 20: <= 389, N = 74: ~500 per pass -- or crawl at an indefinite point with delta_w ~ 1e3
    until max_iter (3000 for obca_mpc4: 0.27 s on one wavefront), nothing in between. */
 #define OBCA_PATIENCE(N) (500 + 10 * (N))
-#define OBCA_RESTART_MAX_ITER 300    /* iteration limit of the restart pass: the restarts that succeed take 16-117 iterations (C3 gated,
+#ifndef OBCA_RESTART_MAX_ITER        /* iteration limit of the restart pass: the restarts that succeed take 16-117 iterations at N <= 20 (C3 gated,
                                         C5; tools/restart_study.py), one that does not would otherwise run to max_iter = 3000 */
+#define OBCA_RESTART_MAX_ITER(N) (300 + 10 * (N))
+#endif
 #define OBCA_WINDOW_SPEED_FRAC 0.9
 
 /* Line-search filter capacity: a function of the problem SHAPE only, so that every kernel that can run a shape (and the
@@ -90,6 +92,8 @@ struct ObcaLaunch {
     double* cert_y;        /* [B,R_max + 2 npair] final multipliers (objective units), rows then rotation equalities, or NULL */
     double* soc_ws;        /* [B, n_max + 2 R_max + 2 npair] scratch of the second-order correction (original direction, corrected
                               residuals); NULL switches the correction off (wave kernels; the lane kernel keeps it in its workspace) */
+    double* gm_ws;         /* obca_ipm_kernel_gm (shapes beyond the LDS): per-workgroup slice of the HBM workspace, or NULL        */
+    int64_t gm_stride;     /* doubles per slice                                                                                  */
     ObcaParamsDev prm;
 };
 

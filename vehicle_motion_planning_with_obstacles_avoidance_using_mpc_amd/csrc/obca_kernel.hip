@@ -110,6 +110,7 @@ struct Lay {
     int N, nO, M, NS, n, free_T, variant;
     int r_init, r_dyn, r_term, r_xb, r_ub, r_acc, r_T, r_tx, r_norm, r_dist, r_lam, r_mu, R;
     int npair;
+    int uvs, uvo;             // inputs as the Riccati sweep reads them: u_k = S.uv[uvs * k + uvo .. + 1]
     __device__ __forceinline__ int ip(int k) const { return k * NS; }
     __device__ __forceinline__ int iu(int k) const { return k * NS + 3; }
     __device__ __forceinline__ int il(int k) const { return k * NS + (k < N ? 5 : 3); }
@@ -143,6 +144,10 @@ struct Sh {
     double *FG, *Mall, *mall;
     double *Zk, *Pi0;                        // forward half of the two-sided sweep (four-wavefront kernels)
     double* lsv;                             // line-search scalars parked in LDS across a corrected (second-order) solve
+    // what the serial Riccati sweep reads of the iterate and of the row data: multipliers-side data of the soft rows (init, dyn)
+    // and the inputs u_k / the time scale.  Kernels with everything in LDS alias them to Einv / gh / x; the kernel for shapes
+    // beyond the LDS (obca_ipm_kernel_gm) keeps LDS mirrors, so that the stage-serial sweep never waits for HBM.
+    const double *Es, *gs, *uv, *Tv;
     int* offm;
 };
 
@@ -462,10 +467,30 @@ __device__ double row_jdx(const Lay& L, const Sh& S, const Inst& in, int r) {
 // Row r = lane + 64*j lives in slot j of its owner lane: bounds, slack, elastic pair, multipliers, the row value
 // and the per-iteration linearisation (inverse D's and residuals) never leave registers.  Only what OTHER lanes
 // need goes to LDS: y (gather / curvature), yhat, Einv, ghat (assembly, Riccati).
+#define OBCA_ROW_FIELDS(X) X(s) X(p) X(n) X(zL) X(zU) X(zp) X(zn) X(g) X(dy) X(iDs) X(iDp) X(iDn) X(rs) X(rp) X(rn)
 template <int RPL>
-struct Rows {
-    double s[RPL], p[RPL], n[RPL], zL[RPL], zU[RPL], zp[RPL], zn[RPL], g[RPL], dy[RPL];
-    double iDs[RPL], iDp[RPL], iDn[RPL], rs[RPL], rp[RPL], rn[RPL];
+struct Rows {                    // row state in registers: slot j of this thread is row r = thread + NT * j
+#define X(f) double f##_[RPL];
+    OBCA_ROW_FIELDS(X)
+#undef X
+    __device__ __forceinline__ static constexpr int slots() { return RPL; }
+#define X(f) __device__ __forceinline__ double& f(int j) { return f##_[j]; } \
+             __device__ __forceinline__ double f(int j) const { return f##_[j]; }
+    OBCA_ROW_FIELDS(X)
+#undef X
+};
+// RPL = 0: row state in MEMORY (the HBM workspace of the kernel for shapes beyond the LDS, obca_ipm_kernel_gm): same
+// thread <-> row assignment, any number of slots
+template <>
+struct Rows<0> {
+#define X(f) double* f##_;
+    OBCA_ROW_FIELDS(X)
+#undef X
+    int lane_, nslots_;
+    __device__ __forceinline__ int slots() const { return nslots_; }
+#define X(f) __device__ __forceinline__ double& f(int j) const { return f##_[lane_ + NT * j]; }
+    OBCA_ROW_FIELDS(X)
+#undef X
 };
 
 struct Err { double E, dual, prim, comp; };
@@ -475,19 +500,19 @@ __device__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double 
                           double crotmax, double nusum, int lane) {
     double dual = 0.0, prim = 0.0, comp = 0.0, ysum = 0.0, zsum = 0.0, nz = 0.0, nrow = 0.0;
 #pragma unroll
-    for (int j = 0; j < RPL; ++j) {
+    for (int j = 0; j < W.slots(); ++j) {
         const int r = lane + NT * j;
         if (r < L.R) {
             const double w = row_w(L, r);
             const bool eq = row_iseq(L, r);
             const double lo_ = S.Lb[r], up_ = S.Ub[r];
             const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
-            const double s = W.s[j], y = S.y[r], p = W.p[j], n = W.n[j];
-            const double zL = hasL ? W.zL[j] : 0.0, zU = hasU ? W.zU[j] : 0.0, zp = W.zp[j], zn = W.zn[j];
+            const double s = W.s(j), y = S.y[r], p = W.p(j), n = W.n(j);
+            const double zL = hasL ? W.zL(j) : 0.0, zU = hasU ? W.zU(j) : 0.0, zp = W.zp(j), zn = W.zn(j);
             if (!eq) dual = dmaxabs(dual, -y - zL + zU);
             dual = dmaxabs(dual, rho - y - zp);
             dual = dmaxabs(dual, rho + y - zn);
-            prim = dmaxabs(prim, W.g[j] - (eq ? 0.0 : s) - p + n);
+            prim = dmaxabs(prim, W.g(j) - (eq ? 0.0 : s) - p + n);
             comp = dmaxabs(comp, p * zp - mu);
             comp = dmaxabs(comp, n * zn - mu);
             if (hasL) comp = dmaxabs(comp, (s - lo_) * zL - mu);
@@ -523,19 +548,19 @@ __device__ ErrFirst ipm_errors_first(const Lay& L, const Sh& S, const Rows<RPL>&
                                      double crotmax, double nusum, double th_lane, double nz, double nrow, int lane) {
     double dual = 0.0, prim = 0.0, comp0 = 0.0, compm = 0.0, ysum = 0.0, zsum = 0.0, th = th_lane, pnsum = 0.0, emax = 0.0;
 #pragma unroll
-    for (int j = 0; j < RPL; ++j) {
+    for (int j = 0; j < W.slots(); ++j) {
         const int r = lane + NT * j;
         if (r < L.R) {
             const double w = row_w(L, r);
             const bool eq = row_iseq(L, r);
             const double lo_ = S.Lb[r], up_ = S.Ub[r];
             const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
-            const double s = W.s[j], y = S.y[r], p = W.p[j], n = W.n[j];
-            const double zL = hasL ? W.zL[j] : 0.0, zU = hasU ? W.zU[j] : 0.0, zp = W.zp[j], zn = W.zn[j];
+            const double s = W.s(j), y = S.y[r], p = W.p(j), n = W.n(j);
+            const double zL = hasL ? W.zL(j) : 0.0, zU = hasU ? W.zU(j) : 0.0, zp = W.zp(j), zn = W.zn(j);
             if (!eq) dual = dmaxabs(dual, -y - zL + zU);
             dual = dmaxabs(dual, rho - y - zp);
             dual = dmaxabs(dual, rho + y - zn);
-            const double res = W.g[j] - (eq ? 0.0 : s) - p + n;
+            const double res = W.g(j) - (eq ? 0.0 : s) - p + n;
             prim = dmaxabs(prim, res);
             th += w * fabs(res);
             pnsum += w * (p + n);
@@ -1007,7 +1032,7 @@ __device__ __forceinline__ void lu3_solve(const Lu3& f, double r0, double r1, do
 __device__ __forceinline__ double fg_entry(const Lay& L, const Sh& S, const Inst& in, const double* xv, double h, int k, int e) {
     const int a = e >> 3, b = e & 7;
     const double cs = S.ct[k], sn = S.st[k];
-    const double* u = xv + L.iu(k);
+    const double* u = S.uv + L.uvs * k + L.uvo;
     double v = 0.0;
     if (a < 3) {
         if (b < 3) v = (a == b) ? 1.0 : 0.0;
@@ -1096,13 +1121,13 @@ __device__ __forceinline__ double sym6(const double* P, int a, int b) { return a
 // stage's 5 x 5 block itself (redundant arithmetic is free here, a round trip through LDS is not).
 __device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, int lane, int m) {
     const double* xv = S.x;
-    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double T = L.free_T ? *S.Tv : 1.0;
     const double h = T * in.Ts;
     int bad = 0;
     if (lane < 42) {            // cost-to-arrive at stage 0: the elastic initial condition 1/2 |dp_0 + ghat|^2_{E^-1}
         double v = 0.0;
-        if (lane < 36) { const int a = lane / 6, b = lane - 6 * a; if (a == b && a < 3) v = S.Einv[L.r_init + a]; }
-        else { const int a = lane - 36; if (a < 3) v = S.Einv[L.r_init + a] * S.gh[L.r_init + a]; }
+        if (lane < 36) { const int a = lane / 6, b = lane - 6 * a; if (a == b && a < 3) v = S.Es[L.r_init + a]; }
+        else { const int a = lane - 36; if (a < 3) v = S.Es[L.r_init + a] * S.gs[L.r_init + a]; }
         S.Pi0[lane] = v;
     }
     WSYNC();
@@ -1115,8 +1140,8 @@ __device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, i
         const double* lk = S.lall + 8 * k;
         double D[3], gh[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { D[j] = S.Einv[L.r_dyn + 3 * k + j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
-        const double cs = S.ct[k], sn = S.st[k], u0 = xv[L.iu(k)], u1 = xv[L.iu(k) + 1];
+        for (int j = 0; j < 3; ++j) { D[j] = S.Es[L.r_dyn + 3 * k + j]; gh[j] = S.gs[L.r_dyn + 3 * k + j]; }
+        const double cs = S.ct[k], sn = S.st[k], u0 = S.uv[L.uvs * k + L.uvo], u1 = S.uv[L.uvs * k + L.uvo + 1];
         const double a02 = -h * u0 * sn, a12 = h * u0 * cs;         // d pose' / d theta: A = I + a02 e0 e2' + a12 e1 e2'
         double tc[3] = {0.0, 0.0, 0.0};
         if (L.free_T) { tc[0] = in.Ts * u0 * cs; tc[1] = in.Ts * u0 * sn; tc[2] = in.Ts * u1; }
@@ -1204,7 +1229,7 @@ __device__ __forceinline__ int two_sided_split(const Lay& L, const Sh& S, int la
     int m = L.N >= 4 ? L.N * OBCA_SPLIT_NUM / 20 : 0;
     if (m > 0) {
         double dmax = 0.0;
-        for (int r = L.r_init + (lane & 63); r < L.r_term; r += 64) dmax = fmax(dmax, S.Einv[r]);
+        for (int r = L.r_init + (lane & 63); r < L.r_term; r += 64) dmax = fmax(dmax, S.Es[r]);
         if (wave_max(dmax) > OBCA_TWO_SIDED_DMAX) m = 0;
     }
     return m;
@@ -1220,7 +1245,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
     return 0;
 #endif
     const double* xv = S.x;
-    const double T = L.free_T ? xv[L.iT()] : 1.0;
+    const double T = L.free_T ? *S.Tv : 1.0;
     const double h = T * in.Ts;
     int bad = 0;
 #if OBCA_NT >= 256
@@ -1254,7 +1279,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
         // inverse, the 3x6 product M [Ppp Ppo], the symmetrised 6x6 P~ and a 6x6 quadratic form -- same pivots, same inertia test.
         double E[3], Dv[3], gh[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { Dv[j] = S.Einv[L.r_dyn + 3 * k + j]; E[j] = 1.0 / Dv[j]; gh[j] = S.gh[L.r_dyn + 3 * k + j]; }
+        for (int j = 0; j < 3; ++j) { Dv[j] = S.Es[L.r_dyn + 3 * k + j]; E[j] = 1.0 / Dv[j]; gh[j] = S.gs[L.r_dyn + 3 * k + j]; }
         if (NT == 64 || lane < 64) {        // (four wavefronts: the serial sweep is the first wavefront's job alone --
             // the others would only repeat it and compete for the LDS)
             const double* Pl = S.Pk + 36 * (k + 1);
@@ -1358,7 +1383,7 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
     // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
     double E0[3], D0[3], g0[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { D0[j] = S.Einv[L.r_init + j]; E0[j] = 1.0 / D0[j]; g0[j] = S.gh[L.r_init + j]; }
+    for (int j = 0; j < 3; ++j) { D0[j] = S.Es[L.r_init + j]; E0[j] = 1.0 / D0[j]; g0[j] = S.gs[L.r_init + j]; }
     Lu3 lu0;
     double s1[3] = {0.0, 0.0, 0.0}, X55 = 1.0, qt5 = 0.0;
     if (m == 0) {
@@ -1473,14 +1498,14 @@ __device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool
 #pragma unroll
             for (int c = 0; c < 6; ++c) P1[6 * a + c] = S.Pk[36 * (k + 1) + 6 * a + c];
             q1[a] = S.qk[6 * (k + 1) + a];
-            E[a] = S.Einv[L.r_dyn + 3 * k + a];
-            gh[a] = S.gh[L.r_dyn + 3 * k + a];
+            E[a] = S.Es[L.r_dyn + 3 * k + a];
+            gh[a] = S.gs[L.r_dyn + 3 * k + a];
         }
 #pragma unroll
         for (int a = 0; a < 9; ++a) Mi[a] = S.Mik[9 * k + a];
         const double kap0 = S.kapk[2 * k], kap1 = S.kapk[2 * k + 1];
         const double cs = S.ct[k], sn = S.st[k];
-        const double uk0 = xv[L.iu(k)], uk1 = xv[L.iu(k) + 1];
+        const double uk0 = S.uv[L.uvs * k + L.uvo], uk1 = S.uv[L.uvs * k + L.uvo + 1];
         const double xi[6] = {dp[0], dp[1], dp[2], up[0], up[1], dT};
         double u[2] = {kap0, kap1};
 #pragma unroll
@@ -1588,7 +1613,8 @@ struct ObcaHead {
     double *info, *prof, *warm_z;
     const int32_t* warm_use;
     double warm_mu;
-    double *cert_z, *cert_y, *soc_ws;
+    double *cert_z, *cert_y, *soc_ws, *gm_ws;
+    long long gm_stride;
 };
 
 typedef const __attribute__((address_space(4))) ObcaLaunch ObcaLaunchConst;   // descriptor in HBM, read through the scalar cache
@@ -1607,6 +1633,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         A.ts_opt = uni<U>(Ain.ts_opt); A.status = uni<U>(Ain.status); A.iters = uni<U>(Ain.iters); A.info = uni<U>(Ain.info);
         A.prof = uni<U>(Ain.prof); A.warm_z = uni<U>(Ain.warm_z); A.warm_use = uni<U>(Ain.warm_use); A.warm_mu = uni<U>(Ain.warm_mu);
         A.cert_z = uni<U>(Ain.cert_z); A.cert_y = uni<U>(Ain.cert_y); A.soc_ws = uni<U>(Ain.soc_ws);
+        A.gm_ws = Ain.gm_ws; A.gm_stride = Ain.gm_stride;
     }
     if (inst >= A.B) return;
     if (A.variant[inst] == 0) {                      // masked out by the caller (device-side closed loop)
@@ -1659,31 +1686,58 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     L.r_mu = L.r_lam + (L.N + 1) * L.M;
     L.R = L.r_mu + (L.N + 1) * 4 * L.nO;
 
-    // ---- LDS carve (sizes are the handle-wide maxima computed on the host the same way) -----------------
+    // ---- carve (sizes are the handle-wide maxima computed on the host the same way).  GM (rows in memory, RPL = 0): only what
+    // the stage-serial sweep touches -- O(N) doubles -- lives in LDS, everything that grows with the number of rows or
+    // variables in this instance's slice of the HBM workspace (stays in L2: ~1 MB per instance at N = 74) -----------------
+    constexpr bool GM = (RPL == 0);
     Sh S;
+    Rows<RPL> W;
     {
         double* p = smem;
-        auto take = [&](int cnt) { double* q = p; p += (cnt + 1) & ~1; return q; };
+        double* q = nullptr;
+        if constexpr (GM) q = A.gm_ws + (size_t)blockIdx.x * (size_t)A.gm_stride;
+        auto take = [&](int cnt) { double* r = p; p += (cnt + 1) & ~1; return r; };
+        auto takeG = [&](int cnt) { if constexpr (!GM) { double* r = p; p += (cnt + 1) & ~1; return r; } else { double* r = q; q += (cnt + 1) & ~1; return r; } };
         const int nmax = A.n_max, Rmax = A.R_max, np = L.npair, N1 = L.N + 1;
-        S.x = take(nmax); S.dx = take(nmax > 120 ? nmax : 120); S.gf = take(5 * N1 + 1); S.bx = take(nmax);
-        S.y = take(Rmax); S.Einv = take(Rmax); S.gh = take(Rmax); S.Lb = take(Rmax); S.Ub = take(Rmax); S.dy = take(3 * N1 + 3);
-        S.ct = take(N1); S.st = take(N1); S.cc = take(2 * np); S.ctt = take(N1); S.stt = take(N1); S.cct = take(2 * np);
-        S.nu = take(2 * np); S.dnu = take(2 * np); S.crot = take(2 * np);
-        S.Aobs = take(N1 * L.M * 2); S.bobs = take(N1 * L.M); S.xref = take(3 * N1);
+        S.x = takeG(nmax); S.dx = takeG(nmax > 120 ? nmax : 120); S.gf = take(5 * N1 + 1); S.bx = takeG(nmax);
+        S.y = takeG(Rmax); S.Einv = takeG(Rmax); S.gh = takeG(Rmax); S.Lb = takeG(Rmax); S.Ub = takeG(Rmax); S.dy = take(3 * N1 + 3);
+        S.ct = take(N1); S.st = take(N1); S.cc = takeG(2 * np); S.ctt = take(N1); S.stt = take(N1); S.cct = takeG(2 * np);
+        S.nu = takeG(2 * np); S.dnu = takeG(2 * np); S.crot = takeG(2 * np);
+        S.Aobs = takeG(N1 * L.M * 2); S.bobs = takeG(N1 * L.M); S.xref = take(3 * N1);
         S.Lall = take(36 * N1); S.lall = take(8 * N1);
         {   // the trial point xt and the row staging array tmp are only alive while Y (local solutions, from the local
             // blocks to the recovery of the step) is dead, and vice versa: they share its storage
             const int nx = (nmax + 1) & ~1, nr = (Rmax + 1) & ~1, ny = MW * 4 * np;
-            S.Y = take(ny > nx + nr ? ny : nx + nr);
+            S.Y = takeG(ny > nx + nr ? ny : nx + nr);
             S.xt = S.Y; S.tmp = S.Y + nx;
         }
-        S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
+        if constexpr (!GM) {
+            S.Pk = take(36 * N1 > 12 * np ? 36 * N1 : 12 * np);
+            S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
+        } else {
+            S.Pk = take(36 * N1);
+            S.Sloc = takeG(12 * np);
+        }
+        S.qk = take(6 * N1); S.Kk = take(12 * N1); S.kapk = take(2 * N1); S.Mik = take(9 * (N1 + 1));
         // one stage's [F G], the 8 x 8 stage matrix and its gradient are only alive during the backward sweep, when the
-        // step dx (written by the forward pass after it) is not: they share its storage
-        S.FG = S.dx; S.Mall = S.dx + 48; S.mall = S.dx + 112;
+        // step dx (written by the forward pass after it) is not: they share its storage (GM: dx is in HBM, they get their own LDS)
+        if constexpr (!GM) { S.FG = S.dx; } else { S.FG = take(120); }
+        S.Mall = S.FG + 48; S.mall = S.FG + 112;
         S.lsv = take(32);
         S.offm = reinterpret_cast<int*>(take(8));
-        S.Sloc = S.Pk;            // 12 doubles per pair, consumed before the Riccati sweep writes Pk
+        if constexpr (!GM) {
+            S.Es = S.Einv; S.gs = S.gh; S.uv = S.x; S.Tv = S.x + L.iT();
+            L.uvs = L.NS; L.uvo = 3;
+        } else {
+            double* es = take(3 * N1 + 3); double* gs = take(3 * N1 + 3); double* uv = take(2 * N1 + 2);
+            S.Es = es; S.gs = gs; S.uv = uv; S.Tv = uv + 2 * N1;
+            L.uvs = 2; L.uvo = 0;
+            const int ns = (Rmax + NT - 1) / NT, rs = ns * NT;
+            W.lane_ = lane; W.nslots_ = (L.R + NT - 1) / NT;
+#define X(f) W.f##_ = takeG(rs);
+            OBCA_ROW_FIELDS(X)
+#undef X
+        }
     }
     Inst& in = *reinterpret_cast<Inst*>(smem + A.inst_off);
     // two-sided sweep (four-wavefront kernels only: their launches ask for OBCA_ZK_DOUBLES(N) more LDS, BEHIND everything the
@@ -1730,7 +1784,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     ObcaOptsDev O;
     O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho * rho_mult; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed; O.max_soc = Ain.prm.opt.max_soc;          // by value: A may live in HBM (fused closed-loop kernel)
     const int max_iter_v = L.free_T ? O.max_iter_free : O.max_iter_fixed;
-    const int max_iter_w = from_window ? OBCA_RESTART_MAX_ITER : (Ain.prm.opt.restart ? OBCA_PATIENCE(L.N) : max_iter_v);
+    const int max_iter_w = from_window ? OBCA_RESTART_MAX_ITER(L.N) : (Ain.prm.opt.restart ? OBCA_PATIENCE(L.N) : max_iter_v);
     const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
@@ -1790,7 +1844,6 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     PUT(IV_F, f0);
     double mu = from_window ? OBCA_RESTART_MU : (warm ? A.warm_mu : OBCA_MU_INIT);
     // rows: bounds, slacks with bound push, elastic variables on their 1-d central path
-    Rows<RPL> W;
     {
         int bb = 0;
         // heavy per-row code (the row-type switch) runs in rolled loops that stage through LDS; the unrolled
@@ -1802,11 +1855,11 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             S.tmp[r] = row_value(L, S, in, S.x, S.ct, S.st, S.cc, r);
         }
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {
+        for (int j = 0; j < W.slots(); ++j) {
             const int r = lane + NT * j;
-            W.s[j] = 0.0; W.p[j] = 1.0; W.n[j] = 1.0;
-            W.zL[j] = 0.0; W.zU[j] = 0.0; W.zp[j] = 1.0; W.zn[j] = 1.0; W.g[j] = 0.0; W.dy[j] = 0.0;
-            W.iDs[j] = 0.0; W.iDp[j] = 1.0; W.iDn[j] = 1.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
+            W.s(j) = 0.0; W.p(j) = 1.0; W.n(j) = 1.0;
+            W.zL(j) = 0.0; W.zU(j) = 0.0; W.zp(j) = 1.0; W.zn(j) = 1.0; W.g(j) = 0.0; W.dy(j) = 0.0;
+            W.iDs(j) = 0.0; W.iDp(j) = 1.0; W.iDn(j) = 1.0; W.rs(j) = 0.0; W.rp(j) = 0.0; W.rn(j) = 0.0;
             if (r < L.R) {
                 const double lo = S.Lb[r], up = S.Ub[r];
                 const bool eq = row_iseq(L, r);
@@ -1825,10 +1878,10 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const double a = (mu - rho * rr) / (2.0 * rho);
                 const double en = a + sqrt(a * a + mu * rr / (2.0 * rho));
                 const double ep = rr + en;
-                W.g[j] = g; W.s[j] = s; W.p[j] = ep; W.n[j] = en;
-                W.zp[j] = mu / ep; W.zn[j] = mu / en;
-                W.zL[j] = (!eq && hasL) ? 1.0 : 0.0;
-                W.zU[j] = (!eq && hasU) ? 1.0 : 0.0;
+                W.g(j) = g; W.s(j) = s; W.p(j) = ep; W.n(j) = en;
+                W.zp(j) = mu / ep; W.zn(j) = mu / en;
+                W.zL(j) = (!eq && hasL) ? 1.0 : 0.0;
+                W.zU(j) = (!eq && hasU) ? 1.0 : 0.0;
                 S.y[r] = rho - mu / ep;
             }
         }
@@ -1844,7 +1897,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     // constants of the error scaling: number of bound multipliers and of rows (Topt rows count N+1 times)
     double cnt_nz = 0.0, cnt_rows = 0.0;
 #pragma unroll
-    for (int j = 0; j < RPL; ++j) {
+    for (int j = 0; j < W.slots(); ++j) {
         const int r = lane + NT * j;
         if (r < L.R) {
             const double w = row_w(L, r);
@@ -1936,23 +1989,23 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
 #define ws_dnuo (ws_gsoc + A.R_max)
         const int max_soc = A.soc_ws ? O.max_soc : 0;
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {       // unconditional writes end the live ranges of the last step data,
-            W.dy[j] = 0.0; W.iDs[j] = 0.0; W.iDp[j] = 0.0; W.iDn[j] = 0.0; W.rs[j] = 0.0; W.rp[j] = 0.0; W.rn[j] = 0.0;
+        for (int j = 0; j < W.slots(); ++j) {       // unconditional writes end the live ranges of the last step data,
+            W.dy(j) = 0.0; W.iDs(j) = 0.0; W.iDp(j) = 0.0; W.iDn(j) = 0.0; W.rs(j) = 0.0; W.rp(j) = 0.0; W.rn(j) = 0.0;
         }                                      // so they do not occupy registers across the factorisation
         bool first_try = true;
         int fail = 0;
         const double dw_last = GET(IV_DWLAST);
         for (;;) {
 #pragma unroll
-            for (int j = 0; j < RPL; ++j) {
+            for (int j = 0; j < W.slots(); ++j) {
                 const int r = lane + NT * j;
                 if (r < L.R) {
                     const bool eq = row_iseq(L, r);
                     const double y = S.y[r];
                     const double lo_ = S.Lb[r], up_ = S.Ub[r];
-                    const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], y, W.zL[j], W.zU[j], W.zp[j],
-                                          W.zn[j], mu, rho, delta_w);
-                    const double rg = soc_pass ? ws_gsoc[r] : W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j];
+                    const Lin q = row_lin(lo_, up_, eq, W.s(j), W.p(j), W.n(j), y, W.zL(j), W.zU(j), W.zp(j),
+                                          W.zn(j), mu, rho, delta_w);
+                    const double rg = soc_pass ? ws_gsoc[r] : W.g(j) - (eq ? 0.0 : W.s(j)) - W.p(j) + W.n(j);
                     const double gh = rg + q.rs * q.iDs + q.rp * q.iDp - q.rn * q.iDn;
                     const double Ei = 1.0 / (q.iDs + q.iDp + q.iDn);
                     S.Einv[r] = Ei;
@@ -1960,6 +2013,13 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 }
             }
             SYNC();
+            if constexpr (GM) {     // LDS mirrors of what the stage-serial sweep reads: soft rows' E^-1 and ghat, inputs, time scale
+                double* es = const_cast<double*>(S.Es); double* gs = const_cast<double*>(S.gs); double* uv = const_cast<double*>(S.uv);
+                for (int t = lane; t < L.r_term; t += NT) { es[t] = S.Einv[t]; gs[t] = S.gh[t]; }
+                for (int t = lane; t < 2 * L.N; t += NT) uv[t] = S.x[L.iu(t >> 1) + (t & 1)];
+                if (lane == 0 && L.free_T) uv[2 * (L.N + 1)] = S.x[L.iT()];
+                SYNC();
+            }
             gather_grad<true>(L, S, in, S.bx, lane);
             PROF(2)
             assemble_stages(L, S, in, sf, delta_w, lane);
@@ -2028,40 +2088,40 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         for (int r = lane; r < L.R; r += NT)
             S.tmp[r] = row_soft(L, r) ? S.dy[r] : (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r];
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {
+        for (int j = 0; j < W.slots(); ++j) {
             const int r = lane + NT * j;
             if (r < L.R) {
                 const bool eq = row_iseq(L, r);
                 const double lo_ = S.Lb[r], up_ = S.Ub[r];
             const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
                 const double dy = S.tmp[r];
-                W.dy[j] = dy;
+                W.dy(j) = dy;
                 {   // cached for the line search and the update (not kept live across the factorisation)
-                    const Lin q = row_lin(lo_, up_, eq, W.s[j], W.p[j], W.n[j], S.y[r], W.zL[j], W.zU[j], W.zp[j],
-                                          W.zn[j], mu, rho, delta_w);
-                    W.iDs[j] = q.iDs; W.iDp[j] = q.iDp; W.iDn[j] = q.iDn; W.rs[j] = q.rs; W.rp[j] = q.rp; W.rn[j] = q.rn;
+                    const Lin q = row_lin(lo_, up_, eq, W.s(j), W.p(j), W.n(j), S.y[r], W.zL(j), W.zU(j), W.zp(j),
+                                          W.zn(j), mu, rho, delta_w);
+                    W.iDs(j) = q.iDs; W.iDp(j) = q.iDp; W.iDn(j) = q.iDn; W.rs(j) = q.rs; W.rp(j) = q.rp; W.rn(j) = q.rn;
                 }
                 const double w = row_w(L, r);
-                const double ds = (dy - W.rs[j]) * W.iDs[j];
-                const double dp = (dy - W.rp[j]) * W.iDp[j];
-                const double dn = (-dy - W.rn[j]) * W.iDn[j];
-                const double s = W.s[j], p = W.p[j], n = W.n[j];
-                double gs = eq ? 0.0 : W.rs[j] + S.y[r];
+                const double ds = (dy - W.rs(j)) * W.iDs(j);
+                const double dp = (dy - W.rp(j)) * W.iDp(j);
+                const double dn = (-dy - W.rn(j)) * W.iDn(j);
+                const double s = W.s(j), p = W.p(j), n = W.n(j);
+                double gs = eq ? 0.0 : W.rs(j) + S.y[r];
                 if (hasL) {
-                    const double sl = s - lo_, zL = W.zL[j];
+                    const double sl = s - lo_, zL = W.zL(j);
                     if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
                     const double dz = (mu - zL * ds) / sl - zL;
                     if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
                 }
                 if (hasU) {
-                    const double su = up_ - s, zU = W.zU[j];
+                    const double su = up_ - s, zU = W.zU(j);
                     if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
                     const double dz = (mu + zU * ds) / su - zU;
                     if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
                 }
                 if (dp < 0.0) a_max = fmin(a_max, -tau * p / dp);
                 if (dn < 0.0) a_max = fmin(a_max, -tau * n / dn);
-                const double zp = W.zp[j], zn = W.zn[j];
+                const double zp = W.zp(j), zn = W.zn(j);
                 const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
                 if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
                 if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
@@ -2106,15 +2166,15 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             double th_t = 0.0, phi_t = 0.0;
             for (int r = lane; r < L.R; r += NT) S.tmp[r] = row_value(L, S, in, S.xt, S.ctt, S.stt, S.cct, r);
 #pragma unroll
-            for (int j = 0; j < RPL; ++j) {
+            for (int j = 0; j < W.slots(); ++j) {
                 const int r = lane + NT * j;
                 if (r < L.R) {
                     const bool eq = row_iseq(L, r);
-                    const double dy = W.dy[j], w = row_w(L, r);
+                    const double dy = W.dy(j), w = row_w(L, r);
                     const double lo_ = S.Lb[r], up_ = S.Ub[r];
-                    const double st = eq ? 0.0 : W.s[j] + a_try * (dy - W.rs[j]) * W.iDs[j];
-                    const double pt = W.p[j] + a_try * (dy - W.rp[j]) * W.iDp[j];
-                    const double nt = W.n[j] + a_try * (-dy - W.rn[j]) * W.iDn[j];
+                    const double st = eq ? 0.0 : W.s(j) + a_try * (dy - W.rs(j)) * W.iDs(j);
+                    const double pt = W.p(j) + a_try * (dy - W.rp(j)) * W.iDp(j);
+                    const double nt = W.n(j) + a_try * (-dy - W.rn(j)) * W.iDn(j);
                     const double gt = S.tmp[r];
                     th_t += w * fabs(gt - st - pt + nt);
                     phi_t += w * row_barrier(lo_, up_, eq, st, pt, nt, mu, rho);
@@ -2154,9 +2214,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                     for (int t = lane; t < L.n; t += NT) S.dx[t] = ws_dxo[t];           // back to the original direction
                     for (int t = lane; t < 2 * L.npair; t += NT) S.dnu[t] = ws_dnuo[t];
 #pragma unroll
-                    for (int j = 0; j < RPL; ++j) {
+                    for (int j = 0; j < W.slots(); ++j) {
                         const int r = lane + NT * j;
-                        if (r < L.R) W.dy[j] = ws_dyo[r];
+                        if (r < L.R) W.dy(j) = ws_dyo[r];
                     }
                     use_soc = false;
                     SYNC();
@@ -2168,16 +2228,16 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             if (soc_start || soc_next) {
                 const double cf = soc_start ? alpha : a_try;
 #pragma unroll
-                for (int j = 0; j < RPL; ++j) {
+                for (int j = 0; j < W.slots(); ++j) {
                     const int r = lane + NT * j;
                     if (r < L.R) {
                         const bool eq = row_iseq(L, r);
-                        const double dy = W.dy[j];
-                        const double st = eq ? 0.0 : W.s[j] + a_try * (dy - W.rs[j]) * W.iDs[j];
-                        const double pt = W.p[j] + a_try * (dy - W.rp[j]) * W.iDp[j];
-                        const double nt = W.n[j] + a_try * (-dy - W.rn[j]) * W.iDn[j];
+                        const double dy = W.dy(j);
+                        const double st = eq ? 0.0 : W.s(j) + a_try * (dy - W.rs(j)) * W.iDs(j);
+                        const double pt = W.p(j) + a_try * (dy - W.rp(j)) * W.iDp(j);
+                        const double nt = W.n(j) + a_try * (-dy - W.rn(j)) * W.iDn(j);
                         const double res = S.tmp[r] - st - pt + nt;
-                        const double old = soc_start ? W.g[j] - (eq ? 0.0 : W.s[j]) - W.p[j] + W.n[j] : ws_gsoc[r];
+                        const double old = soc_start ? W.g(j) - (eq ? 0.0 : W.s(j)) - W.p(j) + W.n(j) : ws_gsoc[r];
                         ws_gsoc[r] = cf * old + res;
                         if (soc_start) ws_dyo[r] = dy;
                     }
@@ -2227,39 +2287,39 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         // ---- accept ------------------------------------------------------------------------------------------
         // bound multipliers follow the ORIGINAL direction (step a_z); primal variables, y and nu the accepted one
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {
+        for (int j = 0; j < W.slots(); ++j) {
             const int r = lane + NT * j;
             if (r < L.R) {
                 const bool eq = row_iseq(L, r);
                 const double lo_ = S.Lb[r], up_ = S.Ub[r];
             const bool hasL = !eq && lo_ > -INFINITY, hasU = !eq && up_ < INFINITY;
-                const double dy = W.dy[j];
+                const double dy = W.dy(j);
                 const double dyz = use_soc ? ws_dyo[r] : dy;
-                const double ds = (dy - W.rs[j]) * W.iDs[j];
-                const double dp = (dy - W.rp[j]) * W.iDp[j];
-                const double dn = (-dy - W.rn[j]) * W.iDn[j];
-                const double dsz = (dyz - W.rs[j]) * W.iDs[j];
-                const double dpz = (dyz - W.rp[j]) * W.iDp[j];
-                const double dnz = (-dyz - W.rn[j]) * W.iDn[j];
+                const double ds = (dy - W.rs(j)) * W.iDs(j);
+                const double dp = (dy - W.rp(j)) * W.iDp(j);
+                const double dn = (-dy - W.rn(j)) * W.iDn(j);
+                const double dsz = (dyz - W.rs(j)) * W.iDs(j);
+                const double dpz = (dyz - W.rp(j)) * W.iDp(j);
+                const double dnz = (-dyz - W.rn(j)) * W.iDn(j);
                 const double lo = lo_, up = up_;
-                const double s_old = W.s[j], p_old = W.p[j], n_old = W.n[j];
+                const double s_old = W.s(j), p_old = W.p(j), n_old = W.n(j);
                 const double s = eq ? 0.0 : s_old + a_try * ds, p = p_old + a_try * dp, n = n_old + a_try * dn;
                 const double ks = OBCA_KAPPA_SIGMA;
                 if (hasL) {
-                    const double zL = W.zL[j] + a_z * ((mu - W.zL[j] * dsz) / (s_old - lo) - W.zL[j]);
+                    const double zL = W.zL(j) + a_z * ((mu - W.zL(j) * dsz) / (s_old - lo) - W.zL(j));
                     const double sl = s - lo;
-                    W.zL[j] = fmax(fmin(zL, ks * mu / sl), mu / (ks * sl));
+                    W.zL(j) = fmax(fmin(zL, ks * mu / sl), mu / (ks * sl));
                 }
                 if (hasU) {
-                    const double zU = W.zU[j] + a_z * ((mu + W.zU[j] * dsz) / (up - s_old) - W.zU[j]);
+                    const double zU = W.zU(j) + a_z * ((mu + W.zU(j) * dsz) / (up - s_old) - W.zU(j));
                     const double su = up - s;
-                    W.zU[j] = fmax(fmin(zU, ks * mu / su), mu / (ks * su));
+                    W.zU(j) = fmax(fmin(zU, ks * mu / su), mu / (ks * su));
                 }
-                const double zp = W.zp[j] + a_z * ((mu - W.zp[j] * dpz) / p_old - W.zp[j]);
-                const double zn = W.zn[j] + a_z * ((mu - W.zn[j] * dnz) / n_old - W.zn[j]);
-                W.zp[j] = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
-                W.zn[j] = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
-                W.s[j] = s; W.p[j] = p; W.n[j] = n;
+                const double zp = W.zp(j) + a_z * ((mu - W.zp(j) * dpz) / p_old - W.zp(j));
+                const double zn = W.zn(j) + a_z * ((mu - W.zn(j) * dnz) / n_old - W.zn(j));
+                W.zp(j) = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
+                W.zn(j) = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
+                W.s(j) = s; W.p(j) = p; W.n(j) = n;
                 S.y[r] += a_try * dy;
             }
         }
@@ -2278,9 +2338,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         for (int k = lane; k <= L.N; k += NT) { S.ct[k] = S.ctt[k]; S.st[k] = S.stt[k]; }
         for (int t = lane; t < 2 * L.npair; t += NT) S.cc[t] = S.cct[t];
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {
+        for (int j = 0; j < W.slots(); ++j) {
             const int r = lane + NT * j;
-            if (r < L.R) W.g[j] = S.tmp[r];
+            if (r < L.R) W.g(j) = S.tmp[r];
         }
         PUT(IV_F, f_t);           // objective and its gradient (gf) came with the accepted trial as well
         SYNC();
@@ -2527,4 +2587,8 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches,
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
 extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<3>(A, A2, A3); }
 extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5>(A, A2, A3); }
+// shapes beyond the LDS / beyond 1280 rows (long horizons: N = 74 with five obstacles has 3976 rows): four wavefronts per
+// instance, row state and every O(rows) array in the instance's slice of an HBM workspace (L2 resident), the O(N) blocks of
+// the stage-serial Riccati sweep in LDS
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_gm(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<0>(A, A2, A3); }
 #endif

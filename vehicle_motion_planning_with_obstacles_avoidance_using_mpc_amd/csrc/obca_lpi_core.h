@@ -997,7 +997,7 @@ struct Out { int status, iters, nfact; double f, elastic, E0, ts_opt, sf; };
 LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaOptsDev& O,
                           const double* zwarm = nullptr, double mu_warm = OBCA_MU_INIT, bool from_window = false) {
     const int max_iter_v = L.free_T ? O.max_iter_free : O.max_iter_fixed;
-    const int max_iter_w = from_window ? OBCA_RESTART_MAX_ITER : (O.restart ? OBCA_PATIENCE(L.N) : max_iter_v);
+    const int max_iter_w = from_window ? OBCA_RESTART_MAX_ITER(L.N) : (O.restart ? OBCA_PATIENCE(L.N) : max_iter_v);
     const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;

@@ -37,7 +37,7 @@ class obca:
         m, x0v, u0v, xr, A, b, Tsv, term = pack_reference_call(variant, Ts, N, x0, xref, nObs, vObs, AObs, bObs, u0,
                                                                 terminal_set)
         kw = dict(xL=xL, xU=xU, uL=uL, uU=uU, ego=ego, dmin=dmin)
-        if variant == 6 and not self.restart_obca_mpc6:
+        if (variant == 6 and not self.restart_obca_mpc6) or not getattr(self, "restart_all", True):
             kw["restart"] = -1
         if variant == 4:
             prm = SolverParams(Q_free=Q, R_free=R, P_free=P, **kw)
@@ -47,6 +47,7 @@ class obca:
         out = s.solve(variant, x0v[None], u0v[None], xr[None], A[None], b[None], np.array([Tsv]), term[None], prm)
         torch.cuda.synchronize()
         feas = bool(out.feas[0].item())
+        self.last = dict(status=int(out.status[0]), iters=int(out.iters[0]), f=float(out.info[0, 0]), elastic=float(out.info[0, 1]), E0=float(out.info[0, 2]), nfact=int(out.info[0, 3]))
         x_Opt = out.xopt[0].cpu().numpy()
         u_Opt = out.uopt[0].cpu().numpy()
         return x_Opt, u_Opt, feas, float(out.ts_opt[0].item())

@@ -102,7 +102,7 @@ class BatchSolver:
         if mode is not None:
             self.set_mode(mode)
 
-    MODES = {"auto": 0, "wave": 1, "lane": 2, "multiwave": 3}
+    MODES = {"auto": 0, "wave": 1, "lane": 2, "multiwave": 3, "global": 4}
 
     def set_mode(self, mode):
         """'auto' | 'wave' (one wavefront per instance, LDS) | 'multiwave' (four wavefronts per instance, LDS) |
