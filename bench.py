@@ -178,6 +178,31 @@ def config_c3(B, N=20):
     return res
 
 
+def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66))):
+    """Row N3: the reference's open-loop free-time plan (closedLoop.mpc_openLoop_freeTime, src/closed_loop.py:113-120) as ONE
+    instance through the drop-in `obca` class -- the only timing the reference publishes (src/simulation.py:230-231: N = 74
+    136.69 s, N = 10 3.69 s, hardware unspecified).  Second call timed (the first allocates the handle's workspace)."""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
+    pub = {10: 3.69, 74: 136.69}
+    res = {"workload": "open-loop free-time plan (obca_mpc4, cold start, start/goal-only reference), batch of ONE, host call to host result",
+           "reference_published_s": {"N=10": 3.69, "N=74": 136.69, "source": "src/simulation.py:230-231, hardware unspecified"}}
+    for demo, N in cases:
+        s = obca()
+        cl = closedLoop(problemSetting(demo), solver=s)
+        cl.N_free = N
+        cl.mpc_openLoop_freeTime()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        cl.mpc_openLoop_freeTime()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        res["%s_N%d" % (demo, N)] = {"seconds": dt, "feas": bool(cl.feas), "ipm_iters": s.last["iters"], "status": s.last["status"],
+                                     "Ts_opt": float(cl.Ts_opt), "reference_published_s": pub.get(N)}
+    return res
+
+
 def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop per GPU, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds first .. first+B-1, resident in HBM
@@ -418,7 +443,8 @@ def main():
                 line["independent_solver"] = {"error": repr(e)}
         if dist is None and args.closed_loop_rollouts > 0:
             # secondary figures: a failure in one of them must not cost the headline line
-            extras = (("config_c3", lambda: config_c3(B)),
+            extras = (("open_loop", open_loop),
+                      ("config_c3", lambda: config_c3(B)),
                       ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts, classify=not args.no_cpu_baseline)),
                       # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes
                       ("closed_loop_static", lambda: closed_loop_c5(B, n_dyn=0)),

@@ -221,23 +221,25 @@ def test_history_export_on_the_device_matches_the_mirror_lists():
 
 
 def test_step_queue_schedule_equals_one_workgroup_per_rollout(monkeypatch):
-    """the fused kernel's default schedule hands a rollout from workgroup to workgroup (and XCD to XCD) after every step
-    through HBM with an agent-scope release / acquire; with OBCA_ROLLOUT_QUEUE=0 one workgroup keeps the rollout for life.
-    Same arithmetic on the same data: EVERY word of every output must be equal -- 2048 rollouts of uneven cost (two moving
-    boxes), all 30 steps, i.e. ~55 000 hand-offs under load with warm L1s; then once more with the optional warm start, whose
-    primal vectors travel the same way."""
+    """the fused kernel's schedules hand a rollout from workgroup to workgroup after every round: the default
+    (OBCA_ROLLOUT_QUEUE=2) within the rollout's XCD, whose L2 all its CUs share -- no write-back, only the L1 invalidate of the
+    agent-scope acquire -- and the global queue (=1) from XCD to XCD through HBM with an agent-scope release / acquire; with
+    OBCA_ROLLOUT_QUEUE=0 one workgroup keeps the rollout for life.  Same arithmetic on the same data: EVERY word of every
+    output must be equal -- 2048 rollouts of uneven cost (two moving boxes), all 30 steps, i.e. ~20 000 hand-offs per schedule
+    under load with warm L1s; then once more with the optional warm start, whose primal vectors travel the same way."""
     import torch
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
     w = pack_worlds([make_world_c5(i, n_dyn=2) for i in range(2048)])
     for warm in (None, 0.1):
         outs = []
-        for env in ("1", "0"):
+        for env in ("2", "1", "0"):
             monkeypatch.setenv("OBCA_ROLLOUT_QUEUE", env)
             dr = DeviceRollouts(w, N=5, warm_start=warm) if warm else DeviceRollouts(w, N=5)
             dr.run()
             outs.append({k: v.cpu().numpy() for k, v in dr.read().items()})
             torch.cuda.synchronize()
         for k in outs[0]:
-            assert np.array_equal(outs[0][k], outs[1][k]), (warm, k)
+            assert np.array_equal(outs[0][k], outs[2][k]), ("per-XCD queues", warm, k)
+            assert np.array_equal(outs[1][k], outs[2][k]), ("global queue", warm, k)
         assert outs[0]["steps"].sum() > 40000

@@ -196,13 +196,6 @@ class closedLoop:
             if type == "startGoal_only":
                 ref_x[:, 0] = x0[:3]
                 ref_x[:, 1:] = np.asarray(xF[:3], float)[:, None]
-            elif type == "startGoal_smooth":
-                for k in range(N + 1):
-                    ref_x[0, k] = ((xF[0] - x0[0]) / N) * k + x0[0]
-                    ref_x[1, k] = ((xF[1] - x0[1]) / N) * k + x0[1]
-                    if k >= 1:
-                        ref_x[2, k - 1] = np.arctan2(ref_x[1, k] - ref_x[1, k - 1], ref_x[0, k] - ref_x[0, k - 1])
-                ref_x[2, N] = ref_x[2, N - 1]
             elif type == "A_star" and getattr(self.setting, "ref_path", None) is not None:
                 ref_x = np.array(self.setting.ref_path, dtype=float)      # Monte-Carlo worlds carry their own path
             elif type == "A_star":

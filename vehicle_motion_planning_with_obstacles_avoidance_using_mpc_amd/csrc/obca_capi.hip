@@ -135,7 +135,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
         h->offm[i + 1] = h->M;
     }
     h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
-    h->lds_bytes_mw = h->lds_bytes + 8 * OBCA_ZK_DOUBLES(d->N);
+    h->lds_bytes_mw = h->lds_bytes + 8 * (OBCA_ZK_DOUBLES(d->N) + OBCA_HYB_DOUBLES(h->R_max));
     h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
     h->mw_ok = !(h->lds_bytes_mw + 64 > 160 * 1024 || h->R_max > 1280); // 256 threads x 3 or 5 rows; 32 B of static LDS
     h->lds_bytes_gm = 8 * (gm_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off_gm, h->gm_doubles) + OBCA_ZK_DOUBLES(d->N));

@@ -65,6 +65,9 @@
 
 #define OBCA_INST_DOUBLES 64   /* LDS reserved for the per-instance constant block (struct Inst) */
 #define OBCA_ZK_DOUBLES(N) (36 * (((N) + 1) / 2) + 42)   /* four-wavefront kernels: forward half of the two-sided Riccati sweep */
+/* obca_ipm_kernel_mw_r5 (769 .. 1280 rows, 256 threads): the fifth row slot (rows 1024 .. R_max - 1) lives in LDS behind the
+   block above: 15 doubles per row + one dummy element (Rows<-5> in obca_kernel.hip) */
+#define OBCA_HYB_DOUBLES(R_max) ((R_max) > 768 ? 15 * (((R_max) > 1024 ? (R_max) - 1024 : 0) + 1) + 1 + 1024 : 0)
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
 struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, restart; };

@@ -162,7 +162,7 @@ __device__ __forceinline__ bool row_soft(const Lay& L, int r) { return r < L.r_t
 
 // ---------------------------------------------------------------- model evaluation
 // trig + c = A^T lambda for an iterate held in xv; results into ct/st/cc
-__device__ void eval_geom(const Lay& L, const Sh& S, const double* xv, double* ct, double* st, double* cc,
+__device__ __forceinline__ void eval_geom(const Lay& L, const Sh& S, const double* xv, double* ct, double* st, double* cc,
                           int lane) {
     for (int k = lane; k <= L.N; k += NT) {
         const SinCos sc = dsincos(xv[L.ip(k) + 2]);
@@ -186,7 +186,7 @@ __device__ void eval_geom(const Lay& L, const Sh& S, const double* xv, double* c
 }
 
 // value of elastic row r at iterate xv (geometry arrays must be current)
-__device__ double row_value(const Lay& L, const Sh& S, const Inst& in, const double* xv, const double* ct,
+__device__ __forceinline__ double row_value(const Lay& L, const Sh& S, const Inst& in, const double* xv, const double* ct,
                             const double* st, const double* cc, int r) {
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
@@ -244,7 +244,7 @@ __device__ double row_value(const Lay& L, const Sh& S, const Inst& in, const dou
     }
 }
 
-__device__ void row_bounds(const Lay& L, const Inst& in, int r, double& lo, double& up) {
+__device__ __forceinline__ void row_bounds(const Lay& L, const Inst& in, int r, double& lo, double& up) {
     const double INF = INFINITY;
     if (r < L.r_xb) { lo = 0.0; up = 0.0; return; }
     if (r < L.r_ub) { const int j = (r - L.r_xb) & 1; lo = in.xL[j]; up = in.xU[j]; return; }
@@ -269,7 +269,7 @@ __device__ __forceinline__ void rot_value(const Lay& L, const double* xv, const 
 
 // scaled objective sf*f (all lanes return the same value); optionally its gradient into S.gf
 template <bool GRAD>
-__device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, const double* xv, double sf, int lane) {
+__device__ __forceinline__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, const double* xv, double sf, int lane) {
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts;
     double part = 0.0, gT = 0.0;
@@ -322,7 +322,7 @@ __device__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, cons
 // HAT: multipliers yhat = y + ghat / E of the condensed rows (the soft rows keep y) evaluated on the fly -- storing
 // them cost one more row array in LDS
 template <bool HAT>
-__device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, double* out, int lane) {
+__device__ __forceinline__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, double* out, int lane) {
     auto YM = [&](int r) -> double { return HAT ? S.y[r] + S.gh[r] * S.Einv[r] : S.y[r]; };     // condensed rows
     auto YS = [&](int r) -> double { return S.y[r]; };                                             // init, dyn (soft)
     const double* xv = S.x;
@@ -419,7 +419,7 @@ __device__ void gather_grad(const Lay& L, const Sh& S, const Inst& in, double* o
 }
 
 // J_r dx for the condensed rows (soft rows get their dy from the Riccati sweep)
-__device__ double row_jdx(const Lay& L, const Sh& S, const Inst& in, int r) {
+__device__ __forceinline__ double row_jdx(const Lay& L, const Sh& S, const Inst& in, int r) {
     const double* xv = S.x;
     const double* d = S.dx;
     const double T = L.free_T ? xv[L.iT()] : 1.0;
@@ -493,10 +493,40 @@ struct Rows<0> {
 #undef X
 };
 
+// RPL = -5 (four-wavefront kernel for up to 1280 rows): five slots, the first four in registers, the FIFTH IN LDS.  With 256
+// threads the fifth slot holds rows 1024 .. R-1 only -- 90 of C3's 1114 rows -- but as registers it cost every thread 30 VGPRs
+// and the kernel spilled (144 B of scratch per lane, twelve doubles of row state written and re-read every iteration).  Element
+// i < nl = R_max - 1024 of the block is 15 consecutive doubles (odd stride: consecutive threads fall on different LDS banks);
+// the threads without a fifth row share one dummy element (only the unconditional initialisations ever touch it).
+template <>
+struct Rows<-5> {
+#define X(f) double f##_[4];
+    OBCA_ROW_FIELDS(X)
+#undef X
+    double* m_;
+    double* gl_;        // the row VALUES of the four register slots live in LDS too: gl_[NT j] is row thread + NT j
+    enum {
+#define X(f) K_##f,
+        OBCA_ROW_FIELDS(X)
+#undef X
+        K_N };
+    __device__ __forceinline__ static constexpr int slots() { return 5; }
+#define X(f) __device__ __forceinline__ double& f##R(int j) { return j < 4 ? f##_[j] : m_[K_##f]; } \
+             __device__ __forceinline__ double f##R(int j) const { return j < 4 ? f##_[j] : m_[K_##f]; }
+    OBCA_ROW_FIELDS(X)
+#undef X
+#define X(f) __device__ __forceinline__ double& f(int j) { return f##R(j); } \
+             __device__ __forceinline__ double f(int j) const { return f##R(j); }
+    X(s) X(p) X(n) X(zL) X(zU) X(zp) X(zn) X(dy) X(iDs) X(iDp) X(iDn) X(rs) X(rp) X(rn)
+#undef X
+    __device__ __forceinline__ double& g(int j) { return j < 4 ? gl_[NT * j] : m_[K_g]; }
+    __device__ __forceinline__ double g(int j) const { return j < 4 ? gl_[NT * j] : m_[K_g]; }
+};
+
 struct Err { double E, dual, prim, comp; };
 
 template <int RPL>
-__device__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double mu, double rho, double rxmax,
+__device__ __forceinline__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double mu, double rho, double rxmax,
                           double crotmax, double nusum, int lane) {
     double dual = 0.0, prim = 0.0, comp = 0.0, ysum = 0.0, zsum = 0.0, nz = 0.0, nrow = 0.0;
 #pragma unroll
@@ -544,7 +574,7 @@ __device__ Err ipm_errors(const Lay& L, const Sh& S, const Rows<RPL>& W, double 
 // multipliers and of rows) never change and are passed in.  th_lane carries the lane's rotation-row part of theta in.
 struct ErrFirst { Err e0, em; double th, pnsum, emax; };
 template <int RPL>
-__device__ ErrFirst ipm_errors_first(const Lay& L, const Sh& S, const Rows<RPL>& W, double mu, double rho, double rxmax,
+__device__ __forceinline__ ErrFirst ipm_errors_first(const Lay& L, const Sh& S, const Rows<RPL>& W, double mu, double rho, double rxmax,
                                      double crotmax, double nusum, double th_lane, double nz, double nrow, int lane) {
     double dual = 0.0, prim = 0.0, comp0 = 0.0, compm = 0.0, ysum = 0.0, zsum = 0.0, th = th_lane, pnsum = 0.0, emax = 0.0;
 #pragma unroll
@@ -621,7 +651,7 @@ __device__ __forceinline__ double row_barrier(double lo, double up, bool eq, dou
 
 // ---------------------------------------------------------------- stage-cost assembly (one lane per stage)
 // Lall[k] is the 8x8 symmetric stage matrix over (dp(0:3), du_prev(3:5), dT(5), du(6:8)); lall[k] its gradient.
-__device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, double sf, double dw, int lane) {
+__device__ __forceinline__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, double sf, double dw, int lane) {
     const double* xv = S.x;
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double h = T * in.Ts, ih2 = 1.0 / (h * h);
@@ -757,7 +787,7 @@ __device__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, doubl
 // ---------------------------------------------------------------- level 1: local blocks, one lane per pair
 // Writes Y[pr] = Kloc^-1 [G | rloc] (MW x 4) and Sloc[pr] = (G^T Y_G (3x3), G^T Y_r (3)). Returns 1 on a
 // wrong-sign pivot.
-__device__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw, int lane) {
+__device__ __forceinline__ int local_blocks(const Lay& L, const Sh& S, const Inst& in, double dw, int lane) {
     int bad = 0;
 #ifdef NO_LOCAL
     return 0;
@@ -1119,7 +1149,7 @@ __device__ __forceinline__ double sym6(const double* P, int a, int b) { return a
 // half uses the slots m..N), the recovery map v = -(Z (xi_{k+1}; 1)) of stage k to Zk + 36 k (column c at 5 c).
 // Lane (a, b) of the first 36 produces entry (a, b) of Pi_{k+1}, lanes 36..41 entry a of pi_{k+1}; every lane factors the
 // stage's 5 x 5 block itself (redundant arithmetic is free here, a round trip through LDS is not).
-__device__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, int lane, int m) {
+__device__ __forceinline__ int riccati_forward_half(const Lay& L, const Sh& S, const Inst& in, int lane, int m) {
     const double* xv = S.x;
     const double T = L.free_T ? *S.Tv : 1.0;
     const double h = T * in.Ts;
@@ -1236,10 +1266,10 @@ __device__ __forceinline__ int two_sided_split(const Lay& L, const Sh& S, int la
 }
 #endif
 #ifdef OBCA_PROFILE
-__device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, long long* prof_t, bool allow_two = true) {
+__device__ __forceinline__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, long long* prof_t, bool allow_two = true) {
     long long rlast = wall_clock64();
 #else
-__device__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool allow_two = true) {
+__device__ __forceinline__ int riccati(const Lay& L, const Sh& S, const Inst& in, int lane, bool allow_two = true) {
 #endif
 #ifdef NO_RICCATI
     return 0;
@@ -1743,6 +1773,11 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     // two-sided sweep (four-wavefront kernels only: their launches ask for OBCA_ZK_DOUBLES(N) more LDS, BEHIND everything the
     // other kernels carve, so that one layout serves all): recovery maps of the forward half, cost-to-arrive at stage 0
     S.Zk = smem + A.inst_off + OBCA_INST_DOUBLES; S.Pi0 = S.Zk + 36 * ((L.N + 1) / 2);
+    if constexpr (RPL < 0) {     // fifth row slot in LDS, behind the two-sided sweep's storage (host: OBCA_HYB_DOUBLES)
+        const int nl = A.R_max > 4 * NT ? A.R_max - 4 * NT : 0;
+        W.m_ = S.Zk + OBCA_ZK_DOUBLES(L.N) + 15 * (lane < nl ? lane : nl);
+        W.gl_ = S.Zk + OBCA_ZK_DOUBLES(L.N) + 15 * (nl + 1) + 1 + lane;
+    }
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i <= OBCA_MAX_OBST; ++i) S.offm[i] = Ain.offm[i];     // static indices: A stays in kernarg
@@ -2403,10 +2438,10 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
 // apply.  Every copy reads its OWN descriptor (A2, A3 = further kernel arguments with the same content): were they all
 // to read A, the compiler would merge their identical prologue expressions and keep those values alive across the whole
 // first solve, which showed up as scratch traffic in the hot copy.
-template <int RPL>
-__device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const ObcaLaunch& A2, const ObcaLaunch& A3) {
+template <int RPL, class DESC>
+__device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
     const int inst = blockIdx.x;
-    obca_ipm_body<RPL>(A, inst, 0);
+    obca_ipm_body<RPL, false, DESC>(A, inst, 0);
     if (inst >= A.B) return;
     __syncthreads();                                            // status written by thread 0 of this workgroup
     {
@@ -2415,9 +2450,22 @@ __device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const
     }
     // (straight-line, not a loop over the passes: around a loop the compiler hoists the descriptor loads of the cold copy and
     // the kernel needs 64-256 B of scratch; measured with tools/kernel_resources.py)
-    obca_ipm_body<RPL>(A2, inst, 1);
+    obca_ipm_body<RPL, false, DESC>(A2, inst, 1);
     __syncthreads();
-    obca_ipm_body<RPL>(A3, inst, 2);
+    obca_ipm_body<RPL, false, DESC>(A3, inst, 2);
+}
+// KARG: the descriptors are read through the kernarg segment pointer (constant address space) instead of the by-value
+// parameters.  Which form leaves the allocator more room differs from kernel to kernel (tools/kernel_resources.py): by value
+// the one-wavefront kernels need no scratch (through the pointer 80 B), through the pointer obca_ipm_kernel_mw_r3 needs none
+// (by value 80 B).
+template <int RPL, bool KARG = false>
+__device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const ObcaLaunch& A2, const ObcaLaunch& A3) {
+    if constexpr (KARG) {
+        ObcaLaunchConst* Ap = (ObcaLaunchConst*)__builtin_amdgcn_kernarg_segment_ptr();
+        solve_passes<RPL, ObcaLaunchConst>(Ap[0], Ap[1], Ap[2]);
+    } else {
+        solve_passes<RPL, const ObcaLaunch>(A, A2, A3);
+    }
 }
 
 #if OBCA_NT == 64
@@ -2446,26 +2494,43 @@ __device__ __noinline__ void solve_out_of_line(const ObcaLaunch* Lp, int b, int 
 
 // Scheduling.  A rollout used to be one workgroup's job for its whole life (grid = B): with 4096 rollouts of very different
 // cost on 1024 SIMDs the launch ended 36 % after the ideal sum / slots (tools/gpu_tail_c5.py).  Now the unit of work is ONE
-// ROUND (OBCA_RO_BLOCK consecutive steps) of one rollout: persistent workgroups (one per SIMD) claim items i = round * B +
-// rollout from a global counter, in order -- so every rollout has done round r before any starts round r + 1.  Measured on C5 (tools/gpu_c5_stats.py): 1.43 -> 1.29 s;
-// the workgroups wait 3 % of their time, and what remains of the tail (0.26 s) is the longest single STEPS (an obca_mpc6 that
-// runs into its iteration limit plus the obca_mpc8 after it: up to 0.3 s) where they happen in the last rounds.  The item's workgroup first waits until the rollout's previous round is published (it was claimed B
-// items earlier: practically always long over); rollout state travels between workgroups through HBM with agent-scope
-// release / acquire (the L2s of the XCDs are not coherent with each other inside a kernel).  Same arithmetic on the same
-// data: results identical to the rollout-per-workgroup schedule (sched == NULL), which the lock-step path reproduces too.
-// sched[0]: next item, sched[1]: abort flag (a wait that never ends must not hang the GPU), sched[2 + b]: rounds done.
+// ROUND (OBCA_RO_BLOCK consecutive steps) of one rollout: persistent workgroups (one per SIMD) claim items from a counter, in
+// order -- so every rollout has done round r before any starts round r + 1 -- and the item's workgroup first waits until the
+// rollout's previous round is published (it was claimed a queue length earlier: practically always long over).
+//   qmode 2 (default)  ONE QUEUE PER XCD: rollout b belongs to queue b % 8 and is only ever touched by workgroups that run on
+//           XCD b % 8 (each workgroup asks the hardware where it runs: HW_REG_XCC_ID).  All CUs of an XCD share its L2, so the
+//           rollout's state never has to leave it: the publishing wave drains its stores (vmcnt(0): they are in L2) and sets
+//           the flag, the claiming workgroup invalidates its L1 (agent-scope acquire) -- NO L2 write-back.  With the global
+//           queue below every hand-off wrote back its XCD's dirty lines, mostly other workgroups' live spill slots: 15.7 GB
+//           of HBM writes per C5 launch for 0.25 GB of algorithmic traffic (profiles/r03_pmc_c5_WRITE_SIZE.csv).
+//           Nothing here depends on HOW workgroups are placed: a queue whose XCD received no workgroup is simply left
+//           over, and the host runs the global queue afterwards, which skips every item already done (obca_rollouts_run).
+//   qmode 1 one global queue, items i = round * B + rollout; rollout state travels between XCDs, whose L2s are not coherent
+//           with each other inside a kernel, through HBM: agent-scope release (L2 write-back) / acquire.
+//   qmode 0 (sched == NULL) one workgroup per rollout.
+// Same arithmetic on the same data in every mode: results identical word for word (tests/test_gpu_rollouts.py).
+// sched[0]: next item of the global queue, sched[1]: abort flag (a wait that never ends must not hang the GPU),
+// sched[2 + b]: rounds done by rollout b, sched[2 + B + 16 q]: next item of queue q.
 #define OBCA_RO_SPIN_LIMIT (1 << 24)        /* x ~1 us of s_sleep: ~16 s */
 #ifndef OBCA_RO_BLOCK                       /* consecutive steps of a rollout per item: 1, 2, 3 run the C5 batch in the same 1.28-1.29 s; */
-#define OBCA_RO_BLOCK 3                     /* 3 means a third of the hand-offs (each release writes back its XCD's dirty L2 lines)       */
+#define OBCA_RO_BLOCK 3                     /* 3 means a third of the hand-offs                                                           */
 #endif
+#define OBCA_RO_XCDS 8
+#define OBCA_GETREG_XCC_ID (20 | (0 << 6) | ((4 - 1) << 11))     /* hwreg(HW_REG_XCC_ID, 0, 4) */
 
 template <int RPL>
-__device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* launches, int n_steps, int* sched) {
+__device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
     const int lane = threadIdx.x;
     __shared__ int ro_msg[3];
     // (an item may cover OBCA_RO_BLOCK consecutive steps of its rollout: fewer hand-offs, coarser schedule)
     const int KB = sched ? OBCA_RO_BLOCK : 1;
-    const int total = sched ? ((n_steps + KB - 1) / KB) * D.B : n_steps;
+    // this workgroup's queue: the rollouts q0, q0 + qs, q0 + 2 qs, ... (global queue: all of them)
+    const bool local = sched && qmode == 2;
+    const int q0 = local ? (__builtin_amdgcn_s_getreg(OBCA_GETREG_XCC_ID) & (OBCA_RO_XCDS - 1)) : 0;
+    const int qs = local ? OBCA_RO_XCDS : 1;
+    const int Bq = q0 < D.B ? (D.B - q0 + qs - 1) / qs : 0;
+    int* const next = local ? sched + 2 + D.B + 16 * q0 : sched;
+    const int total = sched ? ((n_steps + KB - 1) / KB) * Bq : n_steps;
 #ifdef OBCA_RO_STATS
     long long st_wait = 0, st_work = 0, st_t = wall_clock64();
     int st_items = 0;
@@ -2475,10 +2540,10 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
         if (sched) {
             if (lane == 0) {
                 int bb = -1, r = 0;
-                const int i = __hip_atomic_fetch_add(&sched[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int i = __hip_atomic_fetch_add(next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (i < total) {
-                    r = i / D.B;
-                    bb = i - r * D.B;
+                    r = i / Bq;
+                    bb = q0 + qs * (i - r * Bq);
                     int spins = 0;
                     // (poll relaxed -- an acquire load in the loop would invalidate this CU's L1 on every turn -- and acquire ONCE below)
                     while (__hip_atomic_load(&sched[2 + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r) {
@@ -2492,7 +2557,9 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
                 }
                 // the rollout's state was written by another workgroup, possibly on another XCD: agent-scope acquire on THIS CU
                 // (drops its L1 lines) before anything of it is read -- also when no waiting was needed
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // (a round an earlier launch has already done -- the global queue run after the per-XCD queues -- is skipped)
+                if (bb >= 0 && __hip_atomic_load(&sched[2 + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > r) bb = -2;
+                else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 ro_msg[0] = bb;
                 ro_msg[2] = r;
             }
@@ -2503,6 +2570,7 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
 #ifdef OBCA_RO_STATS
             { const long long t = wall_clock64(); st_wait += t - st_t; st_t = t; }
 #endif
+            if (b == -2) continue;
             if (b < 0) break;
         } else if (item >= total || b >= D.B) {
             break;
@@ -2546,13 +2614,14 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
         }
         if (!running && !sched) break;
         if (sched) {
-            // publish: every store of this wave drained, then ONE agent-scope release (writes back the XCD's L2), then the flag.
+            // publish: every store of this wave drained (they are in this XCD's L2 then), and -- global queue only: the next
+            // workgroup may sit on another XCD -- ONE agent-scope release (writes back the XCD's L2), then the flag.
             // The explicit wait after the fence restates the one the compiler (ROCm 7.2) drops when it believes the wave has
             // nothing outstanding -- the flag must not overtake the write-back (MI355X guide, inter-workgroup visibility).
             __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (lane == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (!local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&sched[2 + b], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -2563,7 +2632,7 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
     }
 #ifdef OBCA_RO_STATS
     if (sched && lane == 0) {
-        int* o = sched + 2 + D.B + 4 * blockIdx.x;
+        int* o = sched + 2 + D.B + 16 * OBCA_RO_XCDS + 4 * blockIdx.x;
         o[0] = (int)st_wait; o[1] = (int)st_work; o[2] = st_items; o[3] = (int)(wall_clock64() & 0x7fffffff);
     }
 #endif
@@ -2571,22 +2640,22 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
 
 // _r4: every shape of the rollout has <= 256 rows (static obstacles only at N=5); _r6: <= 384 rows
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched) {
-    rollout_fused_body<4>(*Dp, launches, n_steps, sched);
+obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
+    rollout_fused_body<4>(*Dp, launches, n_steps, sched, qmode);
 }
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched) {
-    rollout_fused_body<5>(*Dp, launches, n_steps, sched);
+obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
+    rollout_fused_body<5>(*Dp, launches, n_steps, sched, qmode);
 }
 extern "C" __global__ void __launch_bounds__(64)
-obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched) {
-    rollout_fused_body<6>(*Dp, launches, n_steps, sched);
+obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
+    rollout_fused_body<6>(*Dp, launches, n_steps, sched, qmode);
 }
 
 #else
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<3>(A, A2, A3); }
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<3, true>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<-5, true>(A, A2, A3); }
 // shapes beyond the LDS / beyond 1280 rows (long horizons: N = 74 with five obstacles has 3976 rows): four wavefronts per
 // instance, row state and every O(rows) array in the instance's slice of an HBM workspace (L2 resident), the O(N) blocks of
 // the stage-serial Riccati sweep in LDS

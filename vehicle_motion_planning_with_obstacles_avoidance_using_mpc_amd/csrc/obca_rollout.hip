@@ -8,9 +8,9 @@
 #include "obca_device.h"
 #include "obca_rollout_core.h"
 
-extern "C" __global__ void obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched);
-extern "C" __global__ void obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched);
-extern "C" __global__ void obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched);
+extern "C" __global__ void obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode);
+extern "C" __global__ void obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode);
+extern "C" __global__ void obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode);
 
 namespace {
 
@@ -46,9 +46,9 @@ struct obca_rollouts {
     // fused path: descriptors in HBM for the persistent one-wave-per-rollout kernel (obca_kernel.hip)
     rollout::Dev* dD;
     ObcaLaunch* dL;
-    int32_t* sched;           /* [2 + B] work queue of the fused kernel: next item, abort flag, rounds done per rollout */
+    int32_t* sched;           /* [2 + B + 16 x 8] work queues of the fused kernel: next item (global queue), abort flag, rounds done per rollout, next item of each XCD's queue */
     int n_slots;              /* workgroups the device holds at once (one per SIMD) */
-    int sched_mode;           /* 1: step-granular work queue (default), 0: one workgroup per rollout (OBCA_ROLLOUT_QUEUE=0) */
+    int sched_mode;           /* OBCA_ROLLOUT_QUEUE: 2 step-granular work queue per XCD (default), 1 one global queue, 0 one workgroup per rollout */
     ObcaLaunch hL[2 * rollout::MAX_GROUPS];            // [g]: obca_mpc4 (g = 0) / obca_mpc6, [g + MAX_GROUPS]: obca_mpc8 where obca_mpc6 failed
     bool fused_ok;
     bool queue_ran;           /* the last obca_rollouts_run used the device-side work queue (its abort flag is then checked by read) */
@@ -148,13 +148,13 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
     r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0; r->warm_mu = 0.0;
     if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS))) rc = OBCA_E_NOMEM;
-    r->sched = nullptr; r->n_slots = 1024; r->sched_mode = 1; r->queue_ran = false;
-    if (rc == OBCA_OK && !dev_alloc(r, r->sched, (size_t)d->batch + 2 + 4 * 4096)) rc = OBCA_E_NOMEM;   // (+ per-workgroup statistics of -DOBCA_RO_STATS builds)
+    r->sched = nullptr; r->n_slots = 1024; r->sched_mode = 2; r->queue_ran = false;
+    if (rc == OBCA_OK && !dev_alloc(r, r->sched, (size_t)d->batch + 2 + 16 * 8 + 4 * 4096)) rc = OBCA_E_NOMEM;   // (+ per-workgroup statistics of -DOBCA_RO_STATS builds)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && cus > 0) r->n_slots = 4 * cus;
         else (void)hipGetLastError();
-        if (const char* e = getenv("OBCA_ROLLOUT_QUEUE")) r->sched_mode = atoi(e) != 0;
+        if (const char* e = getenv("OBCA_ROLLOUT_QUEUE")) { const int v = atoi(e); r->sched_mode = v < 0 || v > 2 ? 2 : v; }
     }
     if (rc != OBCA_OK) { obca_rollouts_destroy(r); return rc; }
     *out = r;
@@ -293,7 +293,7 @@ extern "C" int obca_rollouts_debug_stats(obca_rollouts* r, int32_t* out, int n) 
     if (!r || !out || n < 0 || n > 4 * 4096) return OBCA_E_INVAL;
     ObcaDeviceGuard guard(r->dims.device);
     if (!guard.ok) return OBCA_E_HIP;
-    return hipMemcpy(out, r->sched + 2 + r->D.B, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? OBCA_OK : OBCA_E_HIP;
+    return hipMemcpy(out, r->sched + 2 + r->D.B + 16 * 8, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? OBCA_OK : OBCA_E_HIP;
 }
 
 __global__ void rollout_debug_state_kernel(rollout::Dev D, int k, double Ts_opt, double x, double y, double th, int set_pose) {
@@ -338,21 +338,27 @@ extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_st
     if (!guard.ok) return OBCA_E_HIP;
     if (n_steps == 0) return OBCA_OK;
     if (r->fused_ok && r->mode == 0) {
-        // persistent workgroups taking (round, rollout) items from a counter; one workgroup per rollout when the queue is off
+        // persistent workgroups taking (round, rollout) items from a queue (sched_mode 2: one queue per XCD, 1: one global
+        // queue); one workgroup per rollout when the queue is off (0).  After the per-XCD queues the global queue runs once
+        // more: it skips every item already done -- all of them, unless an XCD received no workgroup (nothing in HIP
+        // promises a placement) -- so the result never depends on where the hardware put the workgroups.
         const bool queue = r->sched_mode != 0 && (long long)n_steps * r->D.B < (1ll << 30);
         int* sched = queue ? r->sched : nullptr;
         r->queue_ran = queue;
-        if (queue && hipMemsetAsync(r->sched, 0, sizeof(int32_t) * ((size_t)r->D.B + 2), (hipStream_t)hip_stream) != hipSuccess) return OBCA_E_HIP;
+        if (queue && hipMemsetAsync(r->sched, 0, sizeof(int32_t) * ((size_t)r->D.B + 2 + 16 * 8), (hipStream_t)hip_stream) != hipSuccess) return OBCA_E_HIP;
         const int grid = queue ? (r->D.B < r->n_slots ? r->D.B : r->n_slots) : r->D.B;
-        if (r->rows_max <= 256)
-            hipLaunchKernelGGL(obca_rollout_fused_kernel_r4, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
-                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched);
-        else if (r->rows_max <= 320)
-            hipLaunchKernelGGL(obca_rollout_fused_kernel_r5, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
-                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched);
-        else
-            hipLaunchKernelGGL(obca_rollout_fused_kernel_r6, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
-                               (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched);
+        for (int qmode = queue ? r->sched_mode : 0; ; qmode = 1) {
+            if (r->rows_max <= 256)
+                hipLaunchKernelGGL(obca_rollout_fused_kernel_r4, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                                   (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched, qmode);
+            else if (r->rows_max <= 320)
+                hipLaunchKernelGGL(obca_rollout_fused_kernel_r5, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                                   (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched, qmode);
+            else
+                hipLaunchKernelGGL(obca_rollout_fused_kernel_r6, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
+                                   (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, (int)n_steps, sched, qmode);
+            if (qmode != 2) break;
+        }
         return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
     }
     for (int i = 0; i < n_steps; ++i) {
