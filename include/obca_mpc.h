@@ -167,8 +167,7 @@ int obca_set_mode(obca_handle* h, int mode);
  * roundoff (measured in the kernel: 1e-11..1e-10 of the step's size typically); the one-sided sweep rounds exactly like
  * the one-wavefront kernels.  on = -1 (default): two-sided exactly where the one-wavefront kernels cannot run the
  * shape, so that every shape both kernel families can run gives bit-identical results in both; 0: never; 1: always.
- * Environment override at obca_create: OBCA_TWO_SIDED=-1|0|1.  (OBCA_MW8=1: measured experiment, eight wavefronts per
- * instance for these shapes -- identical iterates, slower; DESIGN.md 4a'.) */
+ * Environment override at obca_create: OBCA_TWO_SIDED=-1|0|1. */
 int obca_set_two_sided_sweep(obca_handle* h, int on);
 
 /* Diagnostic: device buffer [max_batch,20] receiving per-phase shader-clock totals of each instance.
@@ -176,7 +175,8 @@ int obca_set_two_sided_sweep(obca_handle* h, int on);
 void obca_set_profile_buffer(obca_handle* h, double* prof);
 
 /* bytes of LDS one instance needs in the wave-per-instance kernels (> 163840: only the lane kernel runs it); the
- * four-wavefront kernels ask for 8 * (36 * ((N + 1) / 2) + 42) bytes more (forward half of their two-sided Riccati sweep) */
+ * four-wavefront kernels ask for 8 * (36 * ((N + 1) / 2) + 42) bytes more (forward half of their two-sided Riccati sweep),
+ * beyond 768 rows another 8 * (15 * (max(rows - 1024, 0) + 1) + 1025) (fifth row slot and row values, csrc/obca_device.h) */
 int64_t obca_lds_bytes(const obca_dims* dims);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -235,12 +235,14 @@ int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
 
 /* n_steps iterations for every rollout.  Default (mode 0): when every problem shape fits the wave kernel, ONE launch
  * of a persistent kernel (harness on lane 0, solves on the wave) whose workgroups -- one per SIMD -- take (round, rollout)
- * items (a round = three consecutive steps) from a device-side counter: every rollout has done round r before any starts
- * round r + 1, rollouts advance
- * independently instead of in lock step (one expensive solve does not hold the batch back), and the launch does not end
- * with a few long rollouts on an otherwise idle GPU.  Results are identical to n_steps calls of obca_rollouts_step.
- * OBCA_ROLLOUT_QUEUE=0 at obca_rollouts_create: one workgroup per rollout for all its steps (the earlier schedule).
- * Mode 1 forces the lock-step launches. */
+ * items (a round = three consecutive steps) from a device-side queue: every rollout has done round r before any starts
+ * round r + 1, rollouts advance independently instead of in lock step (one expensive solve does not hold the batch back),
+ * and the launch does not end with a few long rollouts on an otherwise idle GPU.  There is one queue per XCD (rollout b
+ * belongs to queue b % 8 and is only handled by workgroups running on that XCD, so its state is handed on inside the XCD's
+ * L2 without a write-back), followed by one pass of a global queue that skips every item already done.  Results are
+ * identical to n_steps calls of obca_rollouts_step.  OBCA_ROLLOUT_QUEUE at obca_rollouts_create: 2 (default) as described,
+ * 1 the global queue only (hand-offs through HBM with agent-scope release / acquire), 0 one workgroup per rollout for all
+ * its steps.  Mode 1 forces the lock-step launches. */
 int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_stream);
 int obca_rollouts_set_mode(obca_rollouts* r, int mode);
 /* Diagnostic (-DOBCA_RO_STATS builds): per persistent workgroup [wait, work (10 ns units), items, end clock], n <= 16384 ints to host */

@@ -1,3 +1,5 @@
+"""dev tool: the C5 closed loop (4096 rollouts, two moving boxes) under the three schedules of the fused kernel
+(OBCA_ROLLOUT_QUEUE = 2 one queue per XCD, 1 one global queue, 0 one workgroup per rollout): time, and every output word equal?"""
 import os, sys, time, torch, numpy as np
 sys.path.insert(0, '.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc

@@ -106,6 +106,22 @@ __device__ __forceinline__ int red_or(int v) { return red_max(v ? 1.0 : 0.0) > 0
 #endif
 
 // ---------------------------------------------------------------- instance layout
+// Reciprocal for the hot divisions (row linearisation, pivots of the local LDL^T and of the 3 x 3 / 2 x 2 Riccati blocks, step
+// lengths): v_rcp_f64 + two Newton steps, <= 1 ulp, five dependent instructions instead of the ~11 of the correctly rounded
+// quotient (v_div_scale x 2, rcp, four fma, mul, fma, v_div_fmas, v_div_fixup).  Arguments are finite, normal and non-zero
+// wherever the result is used (a zero or infinite argument gives NaN, not inf / 0: such pivots are rejected by their sign
+// tests before the reciprocal matters, and trial points are checked with isfinite).  -DOBCA_EXACT_DIV restores 1.0 / d.
+#ifdef OBCA_EXACT_DIV
+__device__ __forceinline__ double rcp64(double d) { return 1.0 / d; }
+#else
+__device__ __forceinline__ double rcp64(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+}
+#endif
+
 struct Lay {
     int N, nO, M, NS, n, free_T, variant;
     int r_init, r_dyn, r_term, r_xb, r_ub, r_acc, r_T, r_tx, r_norm, r_dist, r_lam, r_mu, R;
@@ -189,7 +205,7 @@ __device__ __forceinline__ void eval_geom(const Lay& L, const Sh& S, const doubl
 __device__ __forceinline__ double row_value(const Lay& L, const Sh& S, const Inst& in, const double* xv, const double* ct,
                             const double* st, const double* cc, int r) {
     const double T = L.free_T ? xv[L.iT()] : 1.0;
-    const double h = T * in.Ts;
+    const double h = T * in.Ts, ih = rcp64(h);
     if (r < L.r_dyn) return xv[r] - in.x0[r];
     if (r < L.r_term) {
         const int q = r - L.r_dyn, k = q / 3, j = q - 3 * k;
@@ -214,7 +230,7 @@ __device__ __forceinline__ double row_value(const Lay& L, const Sh& S, const Ins
     if (r < L.r_T) {
         const int q = r - L.r_acc, k = q >> 1, c = q & 1;
         const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
-        return (prev - xv[L.iu(k) + c]) / h;
+        return (prev - xv[L.iu(k) + c]) * ih;
     }
     if (r < L.r_tx) return T;
     if (r < L.r_norm) return xv[L.ip(L.N) + (r - L.r_tx)];
@@ -271,7 +287,7 @@ __device__ __forceinline__ void rot_value(const Lay& L, const double* xv, const 
 template <bool GRAD>
 __device__ __forceinline__ double eval_objective(const Lay& L, const Sh& S, const Inst& in, const double* xv, double sf, int lane) {
     const double T = L.free_T ? xv[L.iT()] : 1.0;
-    const double h = T * in.Ts;
+    const double h = T * in.Ts, ih2 = rcp64(h * h), ih2T = ih2 * rcp64(T);
     double part = 0.0, gT = 0.0;
     for (int k = lane; k <= L.N; k += NT) {
         const double* pk = xv + L.ip(k);
@@ -291,16 +307,16 @@ __device__ __forceinline__ double eval_objective(const Lay& L, const Sh& S, cons
                 const double q0 = un[0] - u[0], q1 = un[1] - u[1];
                 const double s0 = in.R2[0] * q0 + in.R2[1] * q1, s1 = in.R2[2] * q0 + in.R2[3] * q1;
                 const double qq = q0 * s0 + q1 * s1;
-                part += qq / (h * h);
-                g0 -= 2.0 * s0 / (h * h);
-                g1 -= 2.0 * s1 / (h * h);
-                gT += -2.0 * qq / (h * h * T);
+                part += qq * ih2;
+                g0 -= 2.0 * s0 * ih2;
+                g1 -= 2.0 * s1 * ih2;
+                gT += -2.0 * qq * ih2T;
             }
             if (k >= 1) {
                 const double* um = xv + L.iu(k - 1);
                 const double q0 = u[0] - um[0], q1 = u[1] - um[1];
-                g0 += 2.0 * (in.R2[0] * q0 + in.R2[1] * q1) / (h * h);
-                g1 += 2.0 * (in.R2[2] * q0 + in.R2[3] * q1) / (h * h);
+                g0 += 2.0 * (in.R2[0] * q0 + in.R2[1] * q1) * ih2;
+                g1 += 2.0 * (in.R2[2] * q0 + in.R2[3] * q1) * ih2;
             }
             if (GRAD) { S.gf[L.ig(k) + 3] = sf * g0; S.gf[L.ig(k) + 4] = sf * g1; }
         }
@@ -327,7 +343,7 @@ __device__ __forceinline__ void gather_grad(const Lay& L, const Sh& S, const Ins
     auto YS = [&](int r) -> double { return S.y[r]; };                                             // init, dyn (soft)
     const double* xv = S.x;
     const double T = L.free_T ? xv[L.iT()] : 1.0;
-    const double h = T * in.Ts;
+    const double h = T * in.Ts, ih = rcp64(h), iTh = ih * rcp64(T);
     // poses and inputs
     for (int t = lane; t < (L.N + 1) * 5; t += NT) {
         const int k = t / 5, j = t - 5 * k;
@@ -369,8 +385,8 @@ __device__ __forceinline__ void gather_grad(const Lay& L, const Sh& S, const Ins
             const double* yd = S.y + L.r_dyn + 3 * k;
             v -= (c == 0) ? h * (cs * yd[0] + sn * yd[1]) : h * yd[2];
             v += YM(L.r_ub + 2 * k + c);
-            v -= YM(L.r_acc + 2 * k + c) / h;
-            if (k + 1 < L.N) v += YM(L.r_acc + 2 * (k + 1) + c) / h;
+            v -= YM(L.r_acc + 2 * k + c) * ih;
+            if (k + 1 < L.N) v += YM(L.r_acc + 2 * (k + 1) + c) * ih;
             out[L.iu(k) + c] = v;
         }
     }
@@ -409,7 +425,7 @@ __device__ __forceinline__ void gather_grad(const Lay& L, const Sh& S, const Ins
             part -= in.Ts * (u[0] * S.ct[k] * yd[0] + u[0] * S.st[k] * yd[1] + u[1] * yd[2]);
             for (int c = 0; c < 2; ++c) {
                 const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
-                part -= YM(L.r_acc + 2 * k + c) * (prev - u[c]) / (T * h);
+                part -= YM(L.r_acc + 2 * k + c) * (prev - u[c]) * iTh;
             }
         }
         part = red_sum(part);
@@ -424,7 +440,7 @@ __device__ __forceinline__ double row_jdx(const Lay& L, const Sh& S, const Inst&
     const double* d = S.dx;
     const double T = L.free_T ? xv[L.iT()] : 1.0;
     const double dT = L.free_T ? d[L.iT()] : 0.0;
-    const double h = T * in.Ts;
+    const double h = T * in.Ts, ih = rcp64(h), iTh = ih * rcp64(T);
     if (r < L.r_xb) return d[L.ip(L.N) + (r - L.r_term)];
     if (r < L.r_ub) { const int q = r - L.r_xb; return d[L.ip(q >> 1) + (q & 1)]; }
     if (r < L.r_acc) { const int q = r - L.r_ub; return d[L.iu(q >> 1) + (q & 1)]; }
@@ -433,7 +449,7 @@ __device__ __forceinline__ double row_jdx(const Lay& L, const Sh& S, const Inst&
         const double prev = (k == 0) ? in.u0[c] : xv[L.iu(k - 1) + c];
         const double dprev = (k == 0) ? 0.0 : d[L.iu(k - 1) + c];
         const double qq = prev - xv[L.iu(k) + c];
-        return (dprev - d[L.iu(k) + c]) / h - qq / (T * h) * dT;
+        return (dprev - d[L.iu(k) + c]) * ih - qq * iTh * dT;
     }
     if (r < L.r_tx) return dT;
     if (r < L.r_norm) return d[L.ip(L.N) + (r - L.r_tx)];
@@ -624,15 +640,15 @@ __device__ __forceinline__ Lin row_lin(double lo, double up, bool eq, double s, 
                                        double zL, double zU, double zp, double zn, double mu, double rho, double dw) {
     const bool hasL = !eq && lo > -INFINITY, hasU = !eq && up < INFINITY;
     double sig = 0.0, gs = 0.0;
-    if (hasL) { const double isl = 1.0 / (s - lo); sig += zL * isl; gs -= mu * isl; }
-    if (hasU) { const double isu = 1.0 / (up - s); sig += zU * isu; gs += mu * isu; }
+    if (hasL) { const double isl = rcp64(s - lo); sig += zL * isl; gs -= mu * isl; }
+    if (hasU) { const double isu = rcp64(up - s); sig += zU * isu; gs += mu * isu; }
     if (hasL && !hasU) gs += OBCA_KAPPA_D * mu;
     if (hasU && !hasL) gs -= OBCA_KAPPA_D * mu;
-    const double ip = 1.0 / p, inn = 1.0 / n;
+    const double ip = rcp64(p), inn = rcp64(n);
     Lin q;
-    q.iDs = eq ? 0.0 : 1.0 / (sig + dw);
-    q.iDp = 1.0 / (zp * ip + dw);
-    q.iDn = 1.0 / (zn * inn + dw);
+    q.iDs = eq ? 0.0 : rcp64(sig + dw);
+    q.iDp = rcp64(zp * ip + dw);
+    q.iDn = rcp64(zn * inn + dw);
     q.rs = eq ? 0.0 : (-y + gs);
     q.rp = rho - y - mu * ip;
     q.rn = rho + y - mu * inn;
@@ -654,7 +670,7 @@ __device__ __forceinline__ double row_barrier(double lo, double up, bool eq, dou
 __device__ __forceinline__ void assemble_stages(const Lay& L, const Sh& S, const Inst& in, double sf, double dw, int lane) {
     const double* xv = S.x;
     const double T = L.free_T ? xv[L.iT()] : 1.0;
-    const double h = T * in.Ts, ih2 = 1.0 / (h * h);
+    const double h = T * in.Ts, ih = rcp64(h), ih2 = ih * ih, iT = rcp64(T), iTh = iT * ih, iThh = iTh * ih;
     double HTT = 0.0;
     for (int k = lane; k <= L.N; k += NT) {
         // the stage block is accumulated in registers (read-modify-write through LDS serialised ~100 round trips)
@@ -724,12 +740,12 @@ __device__ __forceinline__ void assemble_stages(const Lay& L, const Sh& S, const
                 for (int c = 0; c < 2; ++c) {
                     const double q = (k == 0) ? in.u0[c] - uc[c] : -qb[c];     // u_{k-1} - u_k
                     const double ya = S.y[L.r_acc + 2 * k + c], Ek = S.Einv[L.r_acc + 2 * k + c];
-                    huT[c] += ya / (T * h) + Ek * q / (T * h * h);
-                    HTT += ya * 2.0 * q / (T * T * h) + Ek * q * q / (T * T * h * h);
+                    huT[c] += ya * iTh + Ek * q * iThh;
+                    HTT += ya * 2.0 * q * (iT * iTh) + Ek * q * q * (iTh * iTh);
                     if (k + 1 < L.N) {
                         const double qn = -qa[c];                              // u_k - u_{k+1}
                         const double yn = S.y[L.r_acc + 2 * (k + 1) + c], En = S.Einv[L.r_acc + 2 * (k + 1) + c];
-                        huT[c] += -yn / (T * h) - En * qn / (T * h * h);
+                        huT[c] += -yn * iTh - En * qn * iThh;
                     }
                 }
                 // acceleration cost cross terms
@@ -737,11 +753,11 @@ __device__ __forceinline__ void assemble_stages(const Lay& L, const Sh& S, const
                 for (int a = 0; a < 2; ++a) {
                     const double Ra = in.R2[2 * a] * qa[0] + in.R2[2 * a + 1] * qa[1];
                     const double Rb = in.R2[2 * a] * qb[0] + in.R2[2 * a + 1] * qb[1];
-                    huT[a] += sf * 4.0 * ih2 / T * (Ra - Rb);
+                    huT[a] += sf * 4.0 * ih2 * iT * (Ra - Rb);
                 }
                 if (k + 1 < L.N) {
                     const double qq = qa[0] * (in.R2[0] * qa[0] + in.R2[1] * qa[1]) + qa[1] * (in.R2[2] * qa[0] + in.R2[3] * qa[1]);
-                    HTT += sf * 6.0 * qq * ih2 / (T * T);
+                    HTT += sf * 6.0 * qq * ih2 * (iT * iT);
                 }
             }
         } else {
@@ -872,7 +888,7 @@ __device__ __forceinline__ int local_blocks(const Lay& L, const Sh& S, const Ins
 #pragma unroll
         for (int j = 0; j < MW; ++j) {
             const double d = KP(j, j);
-            dinv[j] = 1.0 / d;
+            dinv[j] = rcp64(d);
 #pragma unroll
             for (int a = 0; a < MW; ++a) {
                 if (a > j) {
@@ -1037,14 +1053,16 @@ __device__ __forceinline__ int lu3_factor(const double* P, int ld, const double*
     const double a10 = P[ld] * E[0], a11 = fma(P[ld + 1], E[1], 1.0), a12 = P[ld + 2] * E[2];
     const double a20 = P[2 * ld] * E[0], a21 = P[2 * ld + 1] * E[1], a22 = fma(P[2 * ld + 2], E[2], 1.0);
     int bad = !(a00 > 0.0);
-    f.l10 = a10 / a00; f.l20 = a20 / a00;
+    f.i0 = rcp64(a00);
+    f.l10 = a10 * f.i0; f.l20 = a20 * f.i0;
     const double b11 = fma(-f.l10, a01, a11), b12 = fma(-f.l10, a02, a12), b21 = fma(-f.l20, a01, a21), b22 = fma(-f.l20, a02, a22);
     bad |= !(b11 > 0.0);
-    f.l21 = b21 / b11;
+    f.i1 = rcp64(b11);
+    f.l21 = b21 * f.i1;
     const double c22 = fma(-f.l21, b12, b22);
     bad |= !(c22 > 0.0);
     f.u01 = a01; f.u02 = a02; f.u12 = b12;
-    f.i0 = 1.0 / a00; f.i1 = 1.0 / b11; f.i2 = 1.0 / c22;
+    f.i2 = rcp64(c22);
     return bad;
 }
 __device__ __forceinline__ void lu3_solve(const Lu3& f, double r0, double r1, double r2, double& x0, double& x1, double& x2) {
@@ -1309,7 +1327,7 @@ __device__ __forceinline__ int riccati(const Lay& L, const Sh& S, const Inst& in
         // inverse, the 3x6 product M [Ppp Ppo], the symmetrised 6x6 P~ and a 6x6 quadratic form -- same pivots, same inertia test.
         double E[3], Dv[3], gh[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { Dv[j] = S.Es[L.r_dyn + 3 * k + j]; E[j] = 1.0 / Dv[j]; gh[j] = S.gs[L.r_dyn + 3 * k + j]; }
+        for (int j = 0; j < 3; ++j) { Dv[j] = S.Es[L.r_dyn + 3 * k + j]; E[j] = rcp64(Dv[j]); gh[j] = S.gs[L.r_dyn + 3 * k + j]; }
         if (NT == 64 || lane < 64) {        // (four wavefronts: the serial sweep is the first wavefront's job alone --
             // the others would only repeat it and compete for the LDS)
             const double* Pl = S.Pk + 36 * (k + 1);
@@ -1371,9 +1389,9 @@ __device__ __forceinline__ int riccati(const Lay& L, const Sh& S, const Inst& in
         // ---- phase B ----------------------------------------------------------------------------------
         if (NT == 64 || lane < 64) {
         const double m00 = S.Mall[LS(6, 6)], m01 = S.Mall[LS(7, 6)], m11 = S.Mall[LS(7, 7)];
-        const double d1 = m11 - m01 * m01 / m00;
+        const double d1 = m11 - m01 * m01 * rcp64(m00);
         if (!(m00 > 0.0) || !(d1 > 0.0)) bad = 1;
-        const double idet = 1.0 / (m00 * d1);
+        const double idet = rcp64(m00 * d1);
         const double i00 = m11 * idet, i01 = -m01 * idet, i11 = m00 * idet;
         if (lane < 42) {
             const int a = (lane < 36) ? lane / 6 : lane - 36, b = (lane < 36) ? lane - 6 * (lane / 6) : 0;
@@ -1413,7 +1431,7 @@ __device__ __forceinline__ int riccati(const Lay& L, const Sh& S, const Inst& in
     // stage 0: du_{-1} = 0, elastic initial condition, then the time scale
     double E0[3], D0[3], g0[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { D0[j] = S.Es[L.r_init + j]; E0[j] = 1.0 / D0[j]; g0[j] = S.gs[L.r_init + j]; }
+    for (int j = 0; j < 3; ++j) { D0[j] = S.Es[L.r_init + j]; E0[j] = rcp64(D0[j]); g0[j] = S.gs[L.r_init + j]; }
     Lu3 lu0;
     double s1[3] = {0.0, 0.0, 0.0}, X55 = 1.0, qt5 = 0.0;
     if (m == 0) {
@@ -1546,15 +1564,16 @@ __device__ __forceinline__ int riccati(const Lay& L, const Sh& S, const Inst& in
         ph[2] = dp[2] + h * u[1] - gh[2];
         if (L.free_T) { ph[0] += in.Ts * uk0 * cs * dT; ph[1] += in.Ts * uk0 * sn * dT; ph[2] += in.Ts * uk1 * dT; }
         double t[3], dn[3], dyv[3];
+        const double iE[3] = {rcp64(E[0]), rcp64(E[1]), rcp64(E[2])};
 #pragma unroll
         for (int a = 0; a < 3; ++a)
-            t[a] = ph[a] - (P1[6 * a + 3] * u[0] + P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]) / E[a];
+            t[a] = ph[a] - (P1[6 * a + 3] * u[0] + P1[6 * a + 4] * u[1] + P1[6 * a + 5] * dT + q1[a]) * iE[a];
         {   // dn = M' t = E M (E^-1 t); here E[] holds the E^-1 of the formula (S.Einv of the dynamics rows)
             Lu3 lf;
             lf.l10 = Mi[0]; lf.l20 = Mi[1]; lf.l21 = Mi[2]; lf.u01 = Mi[3]; lf.u02 = Mi[4]; lf.u12 = Mi[5]; lf.i0 = Mi[6]; lf.i1 = Mi[7]; lf.i2 = Mi[8];
             double m0, m1, m2;
             lu3_solve(lf, E[0] * t[0], E[1] * t[1], E[2] * t[2], m0, m1, m2);
-            dn[0] = m0 / E[0]; dn[1] = m1 / E[1]; dn[2] = m2 / E[2];
+            dn[0] = m0 * iE[0]; dn[1] = m1 * iE[1]; dn[2] = m2 * iE[2];
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -2042,7 +2061,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                                           W.zn(j), mu, rho, delta_w);
                     const double rg = soc_pass ? ws_gsoc[r] : W.g(j) - (eq ? 0.0 : W.s(j)) - W.p(j) + W.n(j);
                     const double gh = rg + q.rs * q.iDs + q.rp * q.iDp - q.rn * q.iDn;
-                    const double Ei = 1.0 / (q.iDs + q.iDp + q.iDn);
+                    const double Ei = rcp64(q.iDs + q.iDp + q.iDn);
                     S.Einv[r] = Ei;
                     S.gh[r] = gh;
                 }
@@ -2142,26 +2161,27 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const double dn = (-dy - W.rn(j)) * W.iDn(j);
                 const double s = W.s(j), p = W.p(j), n = W.n(j);
                 double gs = eq ? 0.0 : W.rs(j) + S.y[r];
+                const double ids = rcp64(ds), ip = rcp64(p), inn = rcp64(n);     // (ids only used under ds != 0)
                 if (hasL) {
                     const double sl = s - lo_, zL = W.zL(j);
-                    if (ds < 0.0) a_max = fmin(a_max, -tau * sl / ds);
-                    const double dz = (mu - zL * ds) / sl - zL;
-                    if (dz < 0.0) a_z = fmin(a_z, -tau * zL / dz);
+                    if (ds < 0.0) a_max = fmin(a_max, -tau * sl * ids);
+                    const double dz = (mu - zL * ds) * rcp64(sl) - zL;
+                    if (dz < 0.0) a_z = fmin(a_z, -tau * zL * rcp64(dz));
                 }
                 if (hasU) {
                     const double su = up_ - s, zU = W.zU(j);
-                    if (ds > 0.0) a_max = fmin(a_max, tau * su / ds);
-                    const double dz = (mu + zU * ds) / su - zU;
-                    if (dz < 0.0) a_z = fmin(a_z, -tau * zU / dz);
+                    if (ds > 0.0) a_max = fmin(a_max, tau * su * ids);
+                    const double dz = (mu + zU * ds) * rcp64(su) - zU;
+                    if (dz < 0.0) a_z = fmin(a_z, -tau * zU * rcp64(dz));
                 }
-                if (dp < 0.0) a_max = fmin(a_max, -tau * p / dp);
-                if (dn < 0.0) a_max = fmin(a_max, -tau * n / dn);
+                if (dp < 0.0) a_max = fmin(a_max, -tau * p * rcp64(dp));
+                if (dn < 0.0) a_max = fmin(a_max, -tau * n * rcp64(dn));
                 const double zp = W.zp(j), zn = W.zn(j);
-                const double dzp = (mu - zp * dp) / p - zp, dzn = (mu - zn * dn) / n - zn;
-                if (dzp < 0.0) a_z = fmin(a_z, -tau * zp / dzp);
-                if (dzn < 0.0) a_z = fmin(a_z, -tau * zn / dzn);
+                const double dzp = (mu - zp * dp) * ip - zp, dzn = (mu - zn * dn) * inn - zn;
+                if (dzp < 0.0) a_z = fmin(a_z, -tau * zp * rcp64(dzp));
+                if (dzn < 0.0) a_z = fmin(a_z, -tau * zn * rcp64(dzn));
                 phi += w * row_barrier(lo_, up_, eq, s, p, n, mu, rho);
-                dphi += w * (gs * ds + (rho - mu / p) * dp + (rho - mu / n) * dn);
+                dphi += w * (gs * ds + (rho - mu * ip) * dp + (rho - mu * inn) * dn);
             }
         }
         for (int t = lane; t < L.n; t += NT) {                       // same lane <-> entry assignment as a dense gradient
@@ -2339,21 +2359,22 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const double lo = lo_, up = up_;
                 const double s_old = W.s(j), p_old = W.p(j), n_old = W.n(j);
                 const double s = eq ? 0.0 : s_old + a_try * ds, p = p_old + a_try * dp, n = n_old + a_try * dn;
-                const double ks = OBCA_KAPPA_SIGMA;
+                const double ks = OBCA_KAPPA_SIGMA, iks = 1.0 / OBCA_KAPPA_SIGMA;
                 if (hasL) {
-                    const double zL = W.zL(j) + a_z * ((mu - W.zL(j) * dsz) / (s_old - lo) - W.zL(j));
-                    const double sl = s - lo;
-                    W.zL(j) = fmax(fmin(zL, ks * mu / sl), mu / (ks * sl));
+                    const double zL = W.zL(j) + a_z * ((mu - W.zL(j) * dsz) * rcp64(s_old - lo) - W.zL(j));
+                    const double msl = mu * rcp64(s - lo);
+                    W.zL(j) = fmax(fmin(zL, ks * msl), msl * iks);
                 }
                 if (hasU) {
-                    const double zU = W.zU(j) + a_z * ((mu + W.zU(j) * dsz) / (up - s_old) - W.zU(j));
-                    const double su = up - s;
-                    W.zU(j) = fmax(fmin(zU, ks * mu / su), mu / (ks * su));
+                    const double zU = W.zU(j) + a_z * ((mu + W.zU(j) * dsz) * rcp64(up - s_old) - W.zU(j));
+                    const double msu = mu * rcp64(up - s);
+                    W.zU(j) = fmax(fmin(zU, ks * msu), msu * iks);
                 }
-                const double zp = W.zp(j) + a_z * ((mu - W.zp(j) * dpz) / p_old - W.zp(j));
-                const double zn = W.zn(j) + a_z * ((mu - W.zn(j) * dnz) / n_old - W.zn(j));
-                W.zp(j) = fmax(fmin(zp, ks * mu / p), mu / (ks * p));
-                W.zn(j) = fmax(fmin(zn, ks * mu / n), mu / (ks * n));
+                const double zp = W.zp(j) + a_z * ((mu - W.zp(j) * dpz) * rcp64(p_old) - W.zp(j));
+                const double zn = W.zn(j) + a_z * ((mu - W.zn(j) * dnz) * rcp64(n_old) - W.zn(j));
+                const double mp = mu * rcp64(p), mn = mu * rcp64(n);
+                W.zp(j) = fmax(fmin(zp, ks * mp), mp * iks);
+                W.zn(j) = fmax(fmin(zn, ks * mn), mn * iks);
                 W.s(j) = s; W.p(j) = p; W.n(j) = n;
                 S.y[r] += a_try * dy;
             }
@@ -2653,9 +2674,15 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches,
 }
 
 #else
+#ifndef OBCA_KARG_R3
+#define OBCA_KARG_R3 true
+#endif
+#ifndef OBCA_KARG_R5
+#define OBCA_KARG_R5 true
+#endif
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<3, true>(A, A2, A3); }
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<-5, true>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<3, OBCA_KARG_R3>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<-5, OBCA_KARG_R5>(A, A2, A3); }
 // shapes beyond the LDS / beyond 1280 rows (long horizons: N = 74 with five obstacles has 3976 rows): four wavefronts per
 // instance, row state and every O(rows) array in the instance's slice of an HBM workspace (L2 resident), the O(N) blocks of
 // the stage-serial Riccati sweep in LDS
