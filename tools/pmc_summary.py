@@ -75,7 +75,8 @@ for tgt, shape in SHAPES.items():
             continue
         mean = lambda v: sum(v) / len(v)
         big = lambda name: [v for v, d_ in zip(e.get(name, []), e["_dur"]) if True]
-        rec = dict(kernel=k, target=tgt, **shape, meta=e["_meta"], launch_ms=mean(e["_dur"]))
+        full = [d_ for d_ in e["_dur"] if d_ >= 0.5 * max(e["_dur"])]     # full-size launches (not warm-ups, not the fused loop's clean-up pass)
+        rec = dict(kernel=k, target=tgt, **shape, meta=e["_meta"], launch_ms=mean(full))
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             fk, wk = max(e["FETCH_SIZE"]), max(e["WRITE_SIZE"])        # the full-size launches (warm-up launches are smaller)
             rec.update(fetch_size_kib=fk, write_size_kib=wk, traffic_bytes=2 * fk * 1024 + wk * 1024,
