@@ -239,7 +239,18 @@ def test_step_queue_schedule_equals_one_workgroup_per_rollout(monkeypatch):
             dr.run()
             outs.append({k: v.cpu().numpy() for k, v in dr.read().items()})
             torch.cuda.synchronize()
+        # the safety net of the per-XCD schedule: an XCD that received no workgroup leaves its queue to the global queue's
+        # clean-up pass.  Placement cannot be forced, so the hook below cuts the per-XCD launch short after 12 steps instead:
+        # the clean-up pass then finds four rounds done and does the other six itself, across the launch boundary
+        monkeypatch.setenv("OBCA_ROLLOUT_QUEUE", "2")
+        monkeypatch.setenv("OBCA_ROLLOUT_LOCAL_STEPS", "12")
+        dr = DeviceRollouts(w, N=5, warm_start=warm) if warm else DeviceRollouts(w, N=5)
+        dr.run()
+        outs.append({k: v.cpu().numpy() for k, v in dr.read().items()})
+        torch.cuda.synchronize()
+        monkeypatch.delenv("OBCA_ROLLOUT_LOCAL_STEPS")
         for k in outs[0]:
             assert np.array_equal(outs[0][k], outs[2][k]), ("per-XCD queues", warm, k)
             assert np.array_equal(outs[1][k], outs[2][k]), ("global queue", warm, k)
+            assert np.array_equal(outs[3][k], outs[2][k]), ("per-XCD queues + clean-up pass", warm, k)
         assert outs[0]["steps"].sum() > 40000
