@@ -235,7 +235,7 @@ int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
 
 /* n_steps iterations for every rollout.  Default (mode 0): when every problem shape fits the wave kernel, ONE launch
  * of a persistent kernel (harness on lane 0, solves on the wave) whose workgroups -- one per SIMD -- take (round, rollout)
- * items (a round = three consecutive steps) from a device-side queue: every rollout has done round r before any starts
+ * items (a round = six consecutive steps) from a device-side queue: every rollout has done round r before any starts
  * round r + 1, rollouts advance independently instead of in lock step (one expensive solve does not hold the batch back),
  * and the launch does not end with a few long rollouts on an otherwise idle GPU.  There is one queue per XCD (rollout b
  * belongs to queue b % 8 and is only handled by workgroups running on that XCD, so its state is handed on inside the XCD's

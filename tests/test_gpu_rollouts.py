@@ -241,7 +241,8 @@ def test_step_queue_schedule_equals_one_workgroup_per_rollout(monkeypatch):
             torch.cuda.synchronize()
         # the safety net of the per-XCD schedule: an XCD that received no workgroup leaves its queue to the global queue's
         # clean-up pass.  Placement cannot be forced, so the hook below cuts the per-XCD launch short after 12 steps instead:
-        # the clean-up pass then finds four rounds done and does the other six itself, across the launch boundary
+        # the clean-up pass then finds the first two rounds (of six steps) done and does the other three itself, across the
+        # launch boundary
         monkeypatch.setenv("OBCA_ROLLOUT_QUEUE", "2")
         monkeypatch.setenv("OBCA_ROLLOUT_LOCAL_STEPS", "12")
         dr = DeviceRollouts(w, N=5, warm_start=warm) if warm else DeviceRollouts(w, N=5)

@@ -330,7 +330,7 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     // shapes that still fit the LDS; the lane kernel for everything else
     // (the choice depends on the SHAPE only, never on the batch size: the answer to an instance must not depend on how many
     // neighbours it was submitted with.  Measured: four wavefronts per instance would shorten launches of B <= 256 by 10-12 %,
-    // tools/gpu_small_batch.py with OBCA_MODE=3 -- callers that want that latency ask for it, as the obca() class does)
+    // measured with OBCA_MODE=3 at batch sizes <= 256 -- callers that want that latency ask for it, as the obca() class does)
     const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw || !lane) {

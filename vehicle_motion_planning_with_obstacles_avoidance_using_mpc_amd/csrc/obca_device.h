@@ -69,6 +69,13 @@
    block above: 15 doubles per row + one dummy element (Rows<-5> in obca_kernel.hip) */
 #define OBCA_HYB_DOUBLES(R_max) ((R_max) > 768 ? 15 * (((R_max) > 1024 ? (R_max) - 1024 : 0) + 1) + 1 + 1024 : 0)
 
+/* Fused closed loop: consecutive steps of one rollout per work item.  Measured on C5 (4096 rollouts x 30 steps, per-XCD
+   queues): 1 / 2 / 3 / 5 / 6 / 10 steps -> 1.112 / 1.101 / 1.083 / 1.060 / 1.050 / 1.141 s: a longer item keeps the rollout's state
+   warm in its CU and needs fewer hand-offs, a too long one leaves the end of the launch to a few workgroups. */
+#ifndef OBCA_RO_BLOCK
+#define OBCA_RO_BLOCK 6
+#endif
+
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
 struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, restart; };
 struct ObcaParamsDev {

@@ -962,84 +962,6 @@ __device__ __forceinline__ int local_blocks(const Lay& L, const Sh& S, const Ins
     return red_or(bad);
 }
 
-// (I + Ppp E)^-1 by LU without pivoting; pivots equal those of I + E^1/2 Ppp E^1/2
-__device__ __forceinline__ int inv3_ipe(const double* P, int ld, const double* E, double Mi[9]) {
-    double A[9];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) { A[3 * a + b] = P[ld * a + b] * E[b] + (a == b ? 1.0 : 0.0); Mi[3 * a + b] = (a == b ? 1.0 : 0.0); }
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (!(A[3 * j + j] > 0.0)) bad = 1;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (i > j) {
-                const double f = A[3 * i + j] / A[3 * j + j];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { A[3 * i + c] -= f * A[3 * j + c]; Mi[3 * i + c] -= f * Mi[3 * j + c]; }
-            }
-        }
-    }
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-        const int j = 2 - jj;
-        const double inv = 1.0 / A[3 * j + j];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Mi[3 * j + c] *= inv;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (i < j) {
-                const double f = A[3 * i + j];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Mi[3 * i + c] -= f * Mi[3 * j + c];
-            }
-    }
-    return bad;
-}
-
-// soft-min of V(p', o) = 1/2 [p';o]'P[p';o] + q'[p';o] against 1/2 (p'-phat)' E^-1 (p'-phat), entirely in
-// registers and redundantly in every lane (no LDS round trip):  X = P~ (symmetric 6x6), qt = q~, Mi = (I+Ppp E)^-1
-__device__ __forceinline__ int soft_min_regs(const double* Pl, const double* ql, const double E[3], double X[36],
-                                             double qt[6], double Mi[9]) {
-    double P[36], q[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) P[i] = Pl[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) q[i] = ql[i];
-    const int bad = inv3_ipe(P, 6, E, Mi);
-    double MP[18];                              // Mi [Ppp Ppo]  (3 x 6)
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) MP[6 * a + c] = Mi[3 * a] * P[c] + Mi[3 * a + 1] * P[6 + c] + Mi[3 * a + 2] * P[12 + c];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) X[6 * a + c] = 0.5 * (MP[6 * a + c] + MP[6 * c + a]);
-#pragma unroll
-        for (int c = 3; c < 6; ++c) { X[6 * a + c] = MP[6 * a + c]; X[6 * c + a] = MP[6 * a + c]; }
-    }
-#pragma unroll
-    for (int a = 3; a < 6; ++a)
-#pragma unroll
-        for (int c = 3; c < 6; ++c) {           // Poo - Pop E (M Ppo)
-            double v = P[6 * a + c];
-#pragma unroll
-            for (int e = 0; e < 3; ++e) v -= P[6 * a + e] * E[e] * MP[6 * e + c];
-            X[6 * a + c] = v;
-        }
-    double Mq[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) Mq[a] = Mi[3 * a] * q[0] + Mi[3 * a + 1] * q[1] + Mi[3 * a + 2] * q[2];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) qt[a] = Mq[a];
-#pragma unroll
-    for (int a = 3; a < 6; ++a) qt[a] = q[a] - (P[6 * a] * E[0] * Mq[0] + P[6 * a + 1] * E[1] * Mq[1] + P[6 * a + 2] * E[2] * Mq[2]);
-    return bad;
-}
-
 // LU of I + Ppp E without pivoting (the pivots are those of I + E^1/2 Ppp E^1/2: all positive iff the elastic dynamics
 // rows leave the value function convex), kept as factors: the sweep never needs the inverse itself, only products of it
 // with a few vectors -- (I + Ppp E)^-1 r by substitution, and its transpose through E (I + Ppp E)^-1 E^-1.
@@ -1117,14 +1039,6 @@ __device__ __forceinline__ double fg_entry(const Lay& L, const Sh& S, const Inst
 #endif
 #define WSYNC() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-// reciprocal by v_rcp_f64 and two Newton steps (the forward half rounds in its own way anyway -- nothing is compared with it
-// bit for bit -- so it does not need the correctly rounded quotient's ten dependent instructions; error <= 1 ulp)
-__device__ __forceinline__ double rcp_nr(double d) {
-    double x = __builtin_amdgcn_rcp(d);
-    x = fma(fma(-d, x, 1.0), x, x);
-    x = fma(fma(-d, x, 1.0), x, x);
-    return x;
-}
 // LDL^T without pivoting of a packed lower triangle (entry (i, j), i >= j, at i (i + 1) / 2 + j), in place: unit factor
 // below the diagonal, reciprocal pivots in id.  Returns 1 on a non-positive pivot.
 template <int n>
@@ -1134,7 +1048,7 @@ __device__ __forceinline__ int ldl_factor(double* s, double* id) {
     for (int j = 0; j < n; ++j) {
         const double d = s[j * (j + 1) / 2 + j];
         bad |= !(d > 0.0);
-        id[j] = rcp_nr(d);
+        id[j] = rcp64(d);
         double c[n];
 #pragma unroll
         for (int i = j + 1; i < n; ++i) c[i] = s[i * (i + 1) / 2 + j];
@@ -2510,11 +2424,9 @@ __device__ __noinline__ int ro_retry(const rollout::Dev* D, int g, int b) { roll
 // (flag in the low half, group in the high half: an out-parameter would be a stack slot, i.e. scratch)
 __device__ __noinline__ long long ro_flag_sel(const rollout::Dev* D, int b) { return ((long long)D->sel[b] << 32) | (unsigned)D->flags[b]; }
 
-template <int RPL>
-__device__ __noinline__ void solve_out_of_line(const ObcaLaunch* Lp, int b, int pass) { obca_ipm_body<RPL, true>(*Lp, b, pass); }
 
 // Scheduling.  A rollout used to be one workgroup's job for its whole life (grid = B): with 4096 rollouts of very different
-// cost on 1024 SIMDs the launch ended 36 % after the ideal sum / slots (tools/gpu_tail_c5.py).  Now the unit of work is ONE
+// cost on 1024 SIMDs the launch ended 36 % after the ideal sum / slots (tools/gpu_tail.py).  Now the unit of work is ONE
 // ROUND (OBCA_RO_BLOCK consecutive steps) of one rollout: persistent workgroups (one per SIMD) claim items from a counter, in
 // order -- so every rollout has done round r before any starts round r + 1 -- and the item's workgroup first waits until the
 // rollout's previous round is published (it was claimed a queue length earlier: practically always long over).
@@ -2533,9 +2445,6 @@ __device__ __noinline__ void solve_out_of_line(const ObcaLaunch* Lp, int b, int 
 // sched[0]: next item of the global queue, sched[1]: abort flag (a wait that never ends must not hang the GPU),
 // sched[2 + b]: rounds done by rollout b, sched[2 + B + 16 q]: next item of queue q.
 #define OBCA_RO_SPIN_LIMIT (1 << 24)        /* x ~1 us of s_sleep: ~16 s */
-#ifndef OBCA_RO_BLOCK                       /* consecutive steps of a rollout per item: 1, 2, 3 run the C5 batch in the same 1.28-1.29 s; */
-#define OBCA_RO_BLOCK 3                     /* 3 means a third of the hand-offs                                                           */
-#endif
 #define OBCA_RO_XCDS 8
 #define OBCA_GETREG_XCC_ID (20 | (0 << 6) | ((4 - 1) << 11))     /* hwreg(HW_REG_XCC_ID, 0, 4) */
 

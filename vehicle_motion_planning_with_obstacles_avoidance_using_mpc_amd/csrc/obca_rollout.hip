@@ -348,9 +348,9 @@ extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_st
         if (queue && hipMemsetAsync(r->sched, 0, sizeof(int32_t) * ((size_t)r->D.B + 2 + 16 * 8), (hipStream_t)hip_stream) != hipSuccess) return OBCA_E_HIP;
         const int grid = queue ? (r->D.B < r->n_slots ? r->D.B : r->n_slots) : r->D.B;
         // test hook (OBCA_ROLLOUT_LOCAL_STEPS = k): the per-XCD queues cover only the first k steps (rounded down to whole
-        // rounds of three), so that the clean-up pass has real work -- the rounds an XCD without workgroups would leave over
+        // rounds), so that the clean-up pass has real work -- the rounds an XCD without workgroups would leave over
         int local_steps = (int)n_steps;
-        if (const char* e = getenv("OBCA_ROLLOUT_LOCAL_STEPS")) { const int v = atoi(e) / 3 * 3; if (v > 0 && v < local_steps) local_steps = v; }
+        if (const char* e = getenv("OBCA_ROLLOUT_LOCAL_STEPS")) { const int v = atoi(e) / OBCA_RO_BLOCK * OBCA_RO_BLOCK; if (v > 0 && v < local_steps) local_steps = v; }
         for (int qmode = queue ? r->sched_mode : 0; ; qmode = 1) {
             const int steps_now = qmode == 2 ? local_steps : (int)n_steps;
             if (r->rows_max <= 256)
