@@ -170,6 +170,7 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
     ObcaDeviceGuard guard(r->dims.device);
     if (!guard.ok) return OBCA_E_HIP;
     hipStream_t s = (hipStream_t)hip_stream;
+    r->queue_ran = false;                  // an aborted work queue of an EARLIER run says nothing about the rollouts started here
     rollout::Dev& D = r->D;
     const size_t B = D.B, N1 = D.Nm + 1, S = D.S, nd = D.n_dyn;
     bool ok = hipMemcpyAsync(r->goal, goal, sizeof(double) * B * 2, hipMemcpyDeviceToDevice, s) == hipSuccess &&
