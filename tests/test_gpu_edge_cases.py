@@ -197,7 +197,10 @@ def test_hbm_workspace_kernel_is_bit_identical_to_the_lds_kernel():
     four-wavefront kernel also runs: same code, same thread <-> row assignment, same arithmetic => identical output words"""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
-    for b, N in ((sc.make_batch(128, 5), 5), (sc.make_batch_c3(48, 20, gated=False), 20), (sc.make_batch_c3(48, 20, gated=True), 20)):
+    # gated at N = 16 / 19 / 20: 899 / 1058 / 1114 rows on obca_ipm_kernel_mw_r5, whose fifth row slot (rows >= 1024) lives in
+    # LDS -- empty at N = 16, 34 and 90 rows at N = 19 and 20
+    for b, N in ((sc.make_batch(128, 5), 5), (sc.make_batch_c3(48, 20, gated=False), 20), (sc.make_batch_c3(48, 20, gated=True), 20),
+                 (sc.make_batch_c3(24, 16, gated=True), 16), (sc.make_batch_c3(24, 19, gated=True), 19)):
         res = []
         for mode in ("multiwave", "global"):
             s = BatchSolver(N, b["m"], max_batch=len(b["variant"]), mode=mode)
