@@ -3,7 +3,10 @@ argument the results are also compared with the lane kernel (independent impleme
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
-from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+import os
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import _lib, scenarios as sc
+if os.environ.get("OBCA_LIB"):      # an alternative build of the library (file name inside the package)
+    _lib.LIB_PATH = os.path.join(_lib.HERE, os.environ["OBCA_LIB"])
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 check = len(sys.argv) > 2

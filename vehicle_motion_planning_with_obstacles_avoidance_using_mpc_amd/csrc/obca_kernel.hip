@@ -1789,7 +1789,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     // Iteration-level scalars that the factorisation never reads are kept in LDS (S.lsv), not in registers: written by
     // thread 0, read back where they are used (a handful of broadcast reads per iteration) -- about 25 registers less
     // across the factorisation, which is what lets the second-order correction fit without scratch.
-    enum { IV_E0 = 11, IV_THMAX, IV_THMIN, IV_EMAX, IV_CNTNZ, IV_CNTROWS, IV_DWLAST, IV_FPREV, IV_F, IV_TAU, IV_N };
+    enum { IV_E0 = 11, IV_THMAX, IV_THMIN, IV_EMAX, IV_CNTNZ, IV_CNTROWS, IV_DWLAST, IV_FPREV, IV_F, IV_TAU, IV_PHIK, IV_N };
 #define PUT(idx, v) do { if (lane == 0) S.lsv[idx] = (v); } while (0)
 #define GET(idx) (S.lsv[idx])
     PUT(IV_E0, INFINITY);
@@ -1882,7 +1882,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     bool f_valid = false;
     double f_th = 0.0, f_phi = 0.0;
     PUT(IV_TAU, fmax(OBCA_TAU_MIN, 1.0 - mu));
-    PUT(IV_DWLAST, 0.0); PUT(IV_EMAX, 0.0);
+    PUT(IV_DWLAST, 0.0); PUT(IV_EMAX, 0.0); PUT(IV_PHIK, NAN);
     int acc_count = 0;
     bool have_prev = false;
 
@@ -1942,6 +1942,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 if (em.E > OBCA_KAPPA_EPS * mu) break;
                 mu = fmax(mu_floor, fmin(OBCA_KAPPA_MU * mu, mu * sqrt(mu)));      // mu^theta_mu, theta_mu = 1.5
                 PUT(IV_TAU, fmax(OBCA_TAU_MIN, 1.0 - mu));
+                PUT(IV_PHIK, NAN);                 // the barrier function has changed
                 f_valid = false;
             }
         }
@@ -2052,6 +2053,10 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         if (!soc_pass && delta_w > 0.0) PUT(IV_DWLAST, delta_w);
         // ---- row steps, step lengths, directional derivative (a corrected solve only needs its own primal step length)
         double a_max = 1.0, a_z = 1.0, dphi = 0.0, phi = 0.0;
+        // phi(x_k): the line search that accepted x_k evaluated it (IPOPT keeps that value too); it is only evaluated again --
+        // one log per row -- when the barrier parameter has changed since, at the first iterate, or in a corrected solve
+        const double phik = GET(IV_PHIK);
+        const bool phi_known = !soc_pass && isfinite(phik);
         const double tau = GET(IV_TAU);
         for (int r = lane; r < L.R; r += NT)
             S.tmp[r] = row_soft(L, r) ? S.dy[r] : (row_jdx(L, S, in, r) + S.gh[r]) * S.Einv[r];
@@ -2094,7 +2099,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                 const double dzp = (mu - zp * dp) * ip - zp, dzn = (mu - zn * dn) * inn - zn;
                 if (dzp < 0.0) a_z = fmin(a_z, -tau * zp * rcp64(dzp));
                 if (dzn < 0.0) a_z = fmin(a_z, -tau * zn * rcp64(dzn));
-                phi += w * row_barrier(lo_, up_, eq, s, p, n, mu, rho);
+                if (!phi_known) phi += w * row_barrier(lo_, up_, eq, s, p, n, mu, rho);
                 dphi += w * (gs * ds + (rho - mu * ip) * dp + (rho - mu * inn) * dn);
             }
         }
@@ -2103,7 +2108,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             if (L.free_T && t == L.iT()) dphi += S.gf[L.igT()] * S.dx[t];
             else if (q < (k < L.N ? 5 : 3)) dphi += S.gf[L.ig(k) + q] * S.dx[t];
         }
-        a_max = red_min(a_max); a_z = red_min(a_z); dphi = red_sum(dphi); phi = red_sum(phi) + GET(IV_F);
+        a_max = red_min(a_max); a_z = red_min(a_z); dphi = red_sum(dphi); phi = phi_known ? phik : red_sum(phi) + GET(IV_F);
         double alpha_min;
         // the two powers of the switching condition do not depend on the step length: once per iteration, not per trial
         double pw_th = 0.0, pw_dphi = 1.0;
@@ -2125,7 +2130,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         soc_pass = false;
         PROF(6)
         // ---- backtracking filter line search ---------------------------------------------------------------
-        double f_t = 0.0;
+        double f_t = 0.0, phi_acc = NAN;
         bool accepted = false, aug = false;
         for (;;) {
             for (int t = lane; t < L.n; t += NT) S.xt[t] = S.x[t] + a_try * S.dx[t];
@@ -2174,7 +2179,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
                     aug = ok;
                 }
             }
-            if (ok) { accepted = true; break; }
+            if (ok) { accepted = true; phi_acc = phi_t; break; }
             // ---- second-order correction bookkeeping (rare)
             const bool fin_eval = isfinite(th_t) && isfinite(f_t);
             bool soc_start = false, soc_next = false;
@@ -2313,6 +2318,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
             if (r < L.R) W.g(j) = S.tmp[r];
         }
         PUT(IV_F, f_t);           // objective and its gradient (gf) came with the accepted trial as well
+        PUT(IV_PHIK, phi_acc);    // and so did the barrier function's value there (valid until the barrier parameter changes)
         SYNC();
         PROF(9)
     }
