@@ -72,9 +72,10 @@ class LpiObca:
     """`obca`-shaped object (reference src/obca.py:828,1361,1564) on the CPU build of the structured core, so that the
     Python ``closedLoop`` mirror can run without a GPU in tests."""
 
-    def __init__(self):
+    def __init__(self, engine="lpi"):
         self.calls = []
         self.restart_obca_mpc6 = True      # as the drop-in obca class (…_amd/obca.py)
+        self.engine = engine               # "lpi": structured core (csrc/obca_lpi_core.h); "oracle": dense C oracle (oracle/obca_oracle.c)
 
     def _solve(self, variant, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, term=None):
         from oracle import c_oracle
@@ -87,8 +88,9 @@ class LpiObca:
             kw.update(Qf=Q, Pf=P, R1f=R[0], R2f=R[1])
         else:
             kw.update(Qx=Q, Px=P, R1x=R[0], R2x=R[1])
-        o = lpi_solve(variant, N, m, x0a[None], u0a[None], xr[None], A[None], b[None], [ts], tm[None],
-                      c_oracle.default_params(**kw))
+        engine = lpi_solve if self.engine == "lpi" else c_oracle.solve_batch
+        o = engine(variant, N, m, x0a[None], u0a[None], xr[None], A[None], b[None], [ts], tm[None],
+                   c_oracle.default_params(**kw))
         self.calls.append(dict(variant=variant, x0=x0a.copy(), u0=u0a.copy(), xref=xr.copy(), A=A.copy(), b=b.copy(), Ts=ts, term=tm.copy(), m=m,
                                status=int(o["status"][0]), info=o["info"][0].copy(), iters=int(o["iters"][0])))
         return o["xopt"][0], o["uopt"][0], bool(o["status"][0] in (0, 1)), float(o["ts_opt"][0])

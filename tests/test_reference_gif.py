@@ -23,9 +23,12 @@ def test_fixture_shape(fx):
     assert ["%.2f" % v for v in t] == fx["spend_time_text"]          # %.2f as src/draw.py:380 prints it
 
 
-def test_structured_core_replays_the_reference_run(fx):
+@pytest.mark.parametrize("engine", ["lpi", "oracle"])
+def test_cpu_solvers_replay_the_reference_run(fx, engine):
+    """engine "oracle": the dense C oracle (oracle/obca_oracle.c) -- this is what pins the ORACLE to the reference;
+    engine "lpi": the structured core the kernels are built from, compiled for the host."""
     n = reference_gif.MATCHED_STEPS
-    cum, xs, cl = reference_gif.replay(native_build.LpiObca(), n)
+    cum, xs, cl = reference_gif.replay(native_build.LpiObca(engine), n)
     assert len(cum) == n
     ref = np.asarray(fx["spend_time"][1:n + 1])
     err = np.abs(cum - ref)
