@@ -203,6 +203,56 @@ def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66))):
     return res
 
 
+def reference_gif_leg():
+    """The one solver output the reference repository holds (its GIF of the demo9 closed loop: sum(Ts_opt[:k]) of 83 chained
+    IPOPT solves, fixture tests/golden/reference_gif_demo9.json) replayed through the product path (closedLoop mirror on the
+    drop-in obca class, one GPU solve per step): how many consecutive steps show the reference's digits."""
+    from tests import reference_gif
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
+    ref = np.asarray(reference_gif.fixture()["spend_time"][1:])
+    out = {"fixture": "tests/golden/reference_gif_demo9.json (83 steps, titles rounded to 0.01 s)", "tolerance_s": reference_gif.TIME_TOL}
+    for name, win in (("cold_start", False), ("window_first", True)):
+        s = obca()
+        s.window_first = win
+        iters = []
+        run = s._run
+        def counted(*a, **k):
+            r = run(*a, **k)
+            iters.append(s.last["iters"])
+            return r
+        s._run = counted
+        t0 = time.perf_counter()
+        cum, _, cl = reference_gif.replay(s, 83)
+        n = min(len(cum), 83)
+        bad = np.where(np.abs(cum[:n] - ref[:n]) > reference_gif.TIME_TOL)[0]
+        out[name] = {"steps_run": int(len(cum)), "consecutive_steps_matching_the_reference": int(bad[0]) if len(bad) else n,
+                     "steps_matching_in_total": int(n - len(bad)), "mean_ipm_iters": float(np.mean(iters)), "seconds": time.perf_counter() - t0}
+    return out
+
+
+def window_first_leg(solver, dv, out0, B, steps=3):
+    """obca_params.restart = 1 on the headline batch: the reference window as the first start (NOT the default -- the reference
+    cold-starts); throughput, and how many instances end at the optimum the default order finds."""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
+    prm1 = SolverParams(restart=1)
+    x0, ts0, st0 = out0.xopt.clone(), out0.ts_opt.clone(), out0.status.clone()
+    go = lambda: solver.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], prm1)
+    o = go()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = go()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ok = (o.status == 0) | (o.status == 1)
+    ok0 = (st0 == 0) | (st0 == 1)
+    both = ok & ok0
+    same = both & ((o.ts_opt - ts0).abs() <= 1e-6 * ts0.abs().clamp(min=1.0)) & ((o.xopt - x0).abs().amax(dim=(1, 2)) <= 1e-5)
+    return {"value": float(ok.sum().item() / dt), "unit": "MPC steps/s", "ms_per_launch": dt * 1e3, "success_rate": float(ok.float().mean().item()),
+            "mean_ipm_iters": float(o.iters.float().mean().item()),
+            "same_optimum_as_the_default_order": int(same.sum().item()), "of_instances_both_solved": int(both.sum().item())}
+
+
 def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False, classify_max=None):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop per GPU, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds first .. first+B-1, resident in HBM
@@ -449,7 +499,9 @@ def main():
                 line["independent_solver"] = {"error": repr(e)}
         if dist is None and args.closed_loop_rollouts > 0:
             # secondary figures: a failure in one of them must not cost the headline line
-            extras = (("open_loop", open_loop),
+            extras = (("reference_gif", reference_gif_leg),
+                      ("window_first", lambda: window_first_leg(solver, dv, out, B)),
+                      ("open_loop", open_loop),
                       ("config_c3", lambda: config_c3(B)),
                       ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts, classify=not args.no_cpu_baseline,
                                                              classify_max=None if args.classify_all else 96)),

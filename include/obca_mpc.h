@@ -67,9 +67,20 @@ typedef struct obca_params {
     int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8                       */
     int32_t max_soc;                   /* [4]     IPOPT max_soc: second-order-correction trials after a rejected first
                                                    trial step; 0 = the default, negative = off              */
-    int32_t restart;                   /* [on]    restart phase (see above); 0 = the default (on), negative = off -- what a
-                                                   driver asks for where its own fallback follows, as obca_mpc8 follows a failed
-                                                   obca_mpc6 in the closed loop (src/closed_loop.py:393-398)  */
+    int32_t restart;                   /* [0]     the starts of a solve:
+                                                     0  (default) the reference's all-zero cold start (src/obca.py:856); the
+                                                        reference window as the second start (restart phase, see above)
+                                                    <0  the cold start only -- what a driver asks for where its own fallback
+                                                        follows, as obca_mpc8 follows a failed obca_mpc6 in the closed loop
+                                                        (src/closed_loop.py:393-398)
+                                                     1  "window first": the reference window as the first start, the cold
+                                                        start as the second.  On the one solver output the reference
+                                                        repository holds (its GIF of the demo9 closed loop: 83 chained
+                                                        IPOPT solves, tests/test_reference_gif.py) this order returns
+                                                        IPOPT's optimum on 69 consecutive steps, the default order on 47
+                                                        (then it settles in a worse local optimum), at a sixth of the
+                                                        interior-point iterations
+                                                     2  the reference window only                                    */
 } obca_params;
 
 typedef struct obca_handle obca_handle;

@@ -17,7 +17,7 @@ class OracleParams(ctypes.Structure):
                [("dmin", ctypes.c_double), ("tol", ctypes.c_double), ("rho", ctypes.c_double),
                 ("feas_tol", ctypes.c_double), ("max_iter_free", ctypes.c_int), ("max_iter_fixed", ctypes.c_int),
                 ("max_soc", ctypes.c_int),          # 0 = IPOPT's default (4 second-order-correction trials), < 0 = off
-                ("restart", ctypes.c_int)]          # 0 = default (restart phase on), < 0 = off
+                ("restart", ctypes.c_int)]          # as obca_params.restart (include/obca_mpc.h): 0, < 0, 1 window first, 2 window only
 
 
 _lib = None

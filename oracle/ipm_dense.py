@@ -172,17 +172,26 @@ def solve(p, opts=None, trace=None):
       inputs describe -- with a ten times larger barrier parameter (IPOPT raises mu to max(mu, ||c||_inf) when it enters
       restoration) converges on 97 % of them.  A genuinely infeasible problem stays infeasible."""
     opts = dict(opts or {})
-    if not opts.get("no_restart"):
-        opts["max_iter"] = min(opts.get("max_iter", options_for(p.variant)["max_iter"]), patience(p.N))
-    r = _solve_once(p, opts, trace)
+    # "window first" (obca_params.restart = 1 / 2, include/obca_mpc.h): the two starts change places
+    win1 = bool(opts.get("window_first"))
+    max_v = opts.get("max_iter", options_for(p.variant)["max_iter"])
     rho0 = opts.get("rho", DEFAULTS["rho"])
+
+    def run(from_window, rho):
+        if from_window:
+            return _solve_once(p, dict(opts, rho=rho, mu_init=RESTART_MU, max_iter=min(restart_max_iter(p.N), max_v)), trace,
+                               x_start=window_start(p))
+        o = dict(opts, rho=rho)
+        if not opts.get("no_restart"):
+            o["max_iter"] = min(max_v, patience(p.N))
+        return _solve_once(p, o, trace)
+
+    r = run(win1, rho0)
     if r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation"):
-        r = _accumulate(_solve_once(p, dict(opts, rho=rho0 * RHO_ESCALATION), trace), r)
+        r = _accumulate(run(win1, rho0 * RHO_ESCALATION), r)
     if r.status not in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS) and not opts.get("no_restart"):
         esc = p.variant == 4 and r.status == STATUS_INFEASIBLE and not opts.get("no_escalation")
-        o3 = dict(opts, rho=rho0 * (RHO_ESCALATION if esc else 1.0), mu_init=RESTART_MU,
-                  max_iter=min(restart_max_iter(p.N), opts.get("max_iter", options_for(p.variant)["max_iter"])))
-        r = _accumulate(_solve_once(p, o3, trace, x_start=window_start(p)), r)
+        r = _accumulate(run(not win1, rho0 * (RHO_ESCALATION if esc else 1.0)), r)
         r.restarted = True
     return r
 

@@ -789,7 +789,7 @@ typedef struct {
     double xL[2], xU[2], uL[2], uU[2], ego[4], dmin, tol, rho, feas_tol;
     int max_iter_free, max_iter_fixed;
     int max_soc;                            /* 0 = IPOPT's default (4), negative = off */
-    int restart;                            /* 0 = default (restart phase on), negative = off */
+    int restart;                            /* as obca_params.restart: 0 default, < 0 cold start only, 1 window first, 2 window only */
 } OracleParams;
 
 static void sym(double* d, const double* s, int k) { for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) d[k * a + b] = 0.5 * (s[k * a + b] + s[k * b + a]); }
@@ -843,25 +843,27 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         o.tol = prm->tol > 0 ? prm->tol : 1e-8; o.rho = prm->rho > 0 ? prm->rho : 1e4; o.feas_tol = prm->feas_tol > 0 ? prm->feas_tol : 1e-6;
         o.max_iter_free = prm->max_iter_free > 0 ? prm->max_iter_free : 3000; o.max_iter_fixed = prm->max_iter_fixed > 0 ? prm->max_iter_fixed : 1000;
         o.max_soc = prm->max_soc == 0 ? 4 : (prm->max_soc < 0 ? 0 : prm->max_soc);
-        o.restart = prm->restart >= 0;
-        status[q] = solve_one(&p, &o, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, 0, MU_INIT);
+        /* prm->restart (include/obca_mpc.h): 0 cold start then window, < 0 cold start only, 1 window then cold start, 2 window only */
+        o.restart = !(prm->restart < 0 || prm->restart == 2);
+        const int win1 = prm->restart >= 1;
+        status[q] = solve_one(&p, &o, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, win1, win1 ? RESTART_MU : MU_INIT);
         if (status[q] == ST_INFEASIBLE && p.variant == 4) {
             /* one penalty escalation for the free-time problem (see oracle/ipm_dense.py:solve): cold start again, rho x 100 */
             Opts o2 = o;
             o2.rho = o.rho * 100.0;
             const int it1 = iters[q];
             const double nf1 = info ? info[(size_t)q * 4 + 3] : 0.0;
-            status[q] = solve_one(&p, &o2, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, 0, MU_INIT);
+            status[q] = solve_one(&p, &o2, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, win1, win1 ? RESTART_MU : MU_INIT);
             iters[q] += it1;
             if (info) info[(size_t)q * 4 + 3] += nf1;
         }
-        if (prm->restart >= 0 && !(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
+        if (o.restart && !(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
             /* restart phase (oracle/ipm_dense.py:solve): once more from the reference window, mu = RESTART_MU */
             Opts o3 = o;
             if (p.variant == 4 && status[q] == ST_INFEASIBLE) o3.rho = o.rho * 100.0;
             const int it1 = iters[q];
             const double nf1 = info ? info[(size_t)q * 4 + 3] : 0.0;
-            status[q] = solve_one(&p, &o3, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, 1, RESTART_MU);
+            status[q] = solve_one(&p, &o3, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, !win1, win1 ? MU_INIT : RESTART_MU);
             iters[q] += it1;
             if (info) info[(size_t)q * 4 + 3] += nf1;
         }

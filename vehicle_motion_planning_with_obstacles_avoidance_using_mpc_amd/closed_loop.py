@@ -254,6 +254,7 @@ class BatchClosedLoop:
         from .solver import BatchSolver, SolverParams
         self._BatchSolver, self._SolverParams = BatchSolver, SolverParams
         self.rollouts = list(rollouts)
+        self.window_first = bool((params_kw or {}).get("window_first"))      # include/obca_mpc.h: restart = 1 / 2
         self.solvers = {}
         self.steps_solved = 0
         self.steps_converged = 0
@@ -274,8 +275,11 @@ class BatchClosedLoop:
         a0 = calls[0][2]
         free = calls[0][1] == 4
         kw = dict(xL=a0[6], xU=a0[7], uL=a0[8], uU=a0[9], ego=a0[16], dmin=a0[15])
+        win1 = self.window_first
         if calls[0][1] == 6:
-            kw["restart"] = -1               # obca_mpc8 follows a failed obca_mpc6 (step()): no restart phase for it
+            kw["restart"] = 2 if win1 else -1   # obca_mpc8 follows a failed obca_mpc6 (step()): one start only
+        elif win1:
+            kw["restart"] = 1
         prm = self._SolverParams(Q_free=a0[2], R_free=a0[3], P_free=a0[1], **kw) if free else \
             self._SolverParams(Q_fix=a0[2], R_fix=a0[3], P_fix=a0[1], **kw)
         st = lambda j: np.stack([p[j] for p in packed])

@@ -289,7 +289,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
     L.prm.opt.max_soc = p->max_soc == 0 ? OBCA_MAX_SOC : (p->max_soc < 0 ? 0 : p->max_soc);
-    L.prm.opt.restart = p->restart < 0 ? 0 : 1;
+    L.prm.opt.restart = OBCA_OPT_RESTART(p->restart); L.prm.opt.start = OBCA_OPT_START(p->restart); L.prm.opt.pad_ = 0;
     if (lds_bytes) *lds_bytes = h->lds_bytes;
     if (wave_ok) *wave_ok = h->wave_ok ? 1 : 0;
     return OBCA_OK;

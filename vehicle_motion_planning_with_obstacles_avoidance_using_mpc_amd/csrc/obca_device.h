@@ -77,7 +77,12 @@
 #endif
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
-struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, restart; };
+/* restart: a second start exists (0 / 1); start: where the FIRST pass begins -- 0 the reference's all-zero cold start (the
+   second start is the reference window then), 1 the reference window (the second start is the cold start).  obca_params.restart
+   carries both (include/obca_mpc.h): OBCA_OPT_RESTART / OBCA_OPT_START decode it the same way everywhere. */
+struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, restart, start, pad_; };
+#define OBCA_OPT_RESTART(r) (((r) < 0 || (r) == 2) ? 0 : 1)
+#define OBCA_OPT_START(r) ((r) >= 1 ? 1 : 0)
 struct ObcaParamsDev {
     ObcaWeightsDev free_time, fixed_time;
     double xL[2], xU[2], uL[2], uU[2];

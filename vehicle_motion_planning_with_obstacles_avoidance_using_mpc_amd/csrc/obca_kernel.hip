@@ -1619,13 +1619,15 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     //           penalty problem, line-search failure, iteration limit, filter full) is repeated from the reference window
     //           with barrier parameter OBCA_RESTART_MU.
     // Every other instance returns here.  A genuinely infeasible problem stays infeasible.
+    // obca_params.restart = 1 / 2 ("window first"): the starts change places -- passes 0 and 1 begin at the reference window,
+    // pass 2 at the reference's cold start.
     double rho_mult = 1.0;
-    bool from_window = false;
+    bool from_window = Ain.prm.opt.start != 0;
     if (pass) {
         const int st0 = __builtin_amdgcn_readfirstlane(A.status[inst]);     // wave-uniform: the flags below stay scalar
         const bool esc = A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE;
         if (pass == 1) { if (!esc) return; }
-        else { if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 == OBCA_STATUS_BAD_BOUNDS || Ain.prm.opt.restart == 0) return; from_window = true; }
+        else { if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 == OBCA_STATUS_BAD_BOUNDS || Ain.prm.opt.restart == 0) return; from_window = !from_window; }
         if (esc) rho_mult = OBCA_RHO_ESCALATION;
     }
 

@@ -1447,14 +1447,18 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     const double dis = (S.xref[0 * N1 + L.N] - in.x0[0]) + (S.xref[1 * N1 + L.N] - in.x0[1]);
     in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
     const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
-    Out o = solve_instance(L, S, in, A.prm.opt, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
+    // obca_params.restart = 1 / 2 ("window first"): the two starts change places (csrc/obca_kernel.hip: obca_ipm_body)
+    const bool win1 = A.prm.opt.start != 0;
+    Out o = win1 ? solve_instance(L, S, in, A.prm.opt, nullptr, OBCA_RESTART_MU, true)
+                 : solve_instance(L, S, in, A.prm.opt, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
     if (o.status == OBCA_STATUS_INFEASIBLE && L.free_T) {
         // one penalty escalation for the free-time problem (the l1 penalty is exact only while rho exceeds the
         // multipliers): the same solve again with rho x 100 -- see csrc/obca_kernel.hip
         ObcaOptsDev O2 = A.prm.opt;
         O2.rho *= OBCA_RHO_ESCALATION;
         const Out o1 = o;
-        o = solve_instance(L, S, in, O2, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
+        o = win1 ? solve_instance(L, S, in, O2, nullptr, OBCA_RESTART_MU, true)
+                 : solve_instance(L, S, in, O2, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
         o.iters += o1.iters; o.nfact += o1.nfact;
     }
     if (A.prm.opt.restart && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
@@ -1463,7 +1467,7 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
         ObcaOptsDev O3 = A.prm.opt;
         if (L.free_T && o.status == OBCA_STATUS_INFEASIBLE) O3.rho *= OBCA_RHO_ESCALATION;
         const Out o1 = o;
-        o = solve_instance(L, S, in, O3, nullptr, OBCA_RESTART_MU, true);
+        o = win1 ? solve_instance(L, S, in, O3) : solve_instance(L, S, in, O3, nullptr, OBCA_RESTART_MU, true);
         o.iters += o1.iters; o.nfact += o1.nfact;
     }
     if (A.warm_z != nullptr && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE)) {

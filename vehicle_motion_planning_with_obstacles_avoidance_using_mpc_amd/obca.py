@@ -20,6 +20,9 @@ class obca:
         # the restart phase of obca_mpc6 (include/obca_mpc.h: restart).  On for a bare call; a driver that answers a failed
         # obca_mpc6 with obca_mpc8 itself (this package's closedLoop) switches it off
         self.restart_obca_mpc6 = True
+        # "window first" (include/obca_mpc.h: restart = 1 / 2): the reference window as the first start of every solve, the
+        # reference's all-zero cold start as the second.  Off by default: the reference cold-starts (src/obca.py:856).
+        self.window_first = False
 
     def _solver(self, N, m):
         key = (int(N), tuple(m))
@@ -37,7 +40,10 @@ class obca:
         m, x0v, u0v, xr, A, b, Tsv, term = pack_reference_call(variant, Ts, N, x0, xref, nObs, vObs, AObs, bObs, u0,
                                                                 terminal_set)
         kw = dict(xL=xL, xU=xU, uL=uL, uU=uU, ego=ego, dmin=dmin)
-        if (variant == 6 and not self.restart_obca_mpc6) or not getattr(self, "restart_all", True):
+        one_start = (variant == 6 and not self.restart_obca_mpc6) or not getattr(self, "restart_all", True)
+        if self.window_first:
+            kw["restart"] = 2 if one_start else 1
+        elif one_start:
             kw["restart"] = -1
         if variant == 4:
             prm = SolverParams(Q_free=Q, R_free=R, P_free=P, **kw)

@@ -48,7 +48,7 @@ class SolverParams:
         self.tol, self.rho, self.feas_tol = float(tol), float(rho), float(feas_tol)
         self.max_iter_free, self.max_iter_fixed = int(max_iter_free), int(max_iter_fixed)
         self.max_soc = int(max_soc)            # 0 = IPOPT's default (4), negative = no second-order correction
-        self.restart = int(restart)            # 0 = restart phase on (default), negative = off (include/obca_mpc.h)
+        self.restart = int(restart)            # 0 cold start then window (default), < 0 cold start only, 1 window first, 2 window only (include/obca_mpc.h)
 
     def to_c(self):
         p = _lib.ObcaParams()
