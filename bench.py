@@ -147,7 +147,7 @@ def cpu_baseline(batch, N):
             "sample": "%d instances of the same batch, structured core (csrc/obca_lpi_core.h) on the host, %d OpenMP threads, %.1f s" % (n, cores, dt)}
 
 
-def config_c3(B, N=20):
+def config_c3(B, N=20, restart=0):
     """Config C3: N=20, walls + box + two moving boxes, lidar-gated: the free-time sub-batch (obca_mpc4, three
     static obstacles) and the gated sub-batch (obca_mpc6, five obstacles, time-varying rows), B UNIQUE seeded instances
     each; both run on the four-wavefront LDS kernel."""
@@ -165,7 +165,7 @@ def config_c3(B, N=20):
         for _ in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = s.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], SolverParams(), out=out)
+            out = s.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], SolverParams(restart=restart), out=out)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
@@ -253,7 +253,7 @@ def window_first_leg(solver, dv, out0, B, steps=3):
             "same_optimum_as_the_default_order": int(same.sum().item()), "of_instances_both_solved": int(both.sum().item())}
 
 
-def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False, classify_max=None):
+def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False, classify_max=None, restart=0):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop per GPU, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds first .. first+B-1, resident in HBM
     before the clock starts.  With a process group every rank runs the whole loop for its own worlds (no collective on
@@ -261,7 +261,11 @@ def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=Fal
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
     w = pack_worlds([sc.make_world_c5(first + i, n_dyn=n_dyn) for i in range(B)])
-    dr = DeviceRollouts(w, N=5, warm_start=warm_start)
+    prm = None
+    if restart:
+        from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
+        prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), restart=restart)
+    dr = DeviceRollouts(w, N=5, warm_start=warm_start, params=prm)
     dr.run(1)
     torch.cuda.synchronize()
     dr.reset()
@@ -499,8 +503,15 @@ def main():
                 line["independent_solver"] = {"error": repr(e)}
         if dist is None and args.closed_loop_rollouts > 0:
             # secondary figures: a failure in one of them must not cost the headline line
+            def window_first_all():
+                r = window_first_leg(solver, dv, out, B)
+                r["note"] = "obca_params.restart = 1: the reference window as the first start of every solve (NOT the default: the reference cold-starts, src/obca.py:856)"
+                r["config_c3"] = config_c3(B, restart=1)
+                c5 = closed_loop_c5(args.closed_loop_rollouts, restart=1)
+                r["closed_loop"] = {k: c5[k] for k in ("value", "unit", "seconds", "converged_steps", "attempted_steps", "rollouts_to_step_cap", "rollouts_stopped_infeasible", "mean_ipm_iters") if k in c5}
+                return r
             extras = (("reference_gif", reference_gif_leg),
-                      ("window_first", lambda: window_first_leg(solver, dv, out, B)),
+                      ("window_first", window_first_all),
                       ("open_loop", open_loop),
                       ("config_c3", lambda: config_c3(B)),
                       ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts, classify=not args.no_cpu_baseline,

@@ -30,10 +30,15 @@ delta_w ladder, dual reset (kappa_sigma 1e10), scaled optimality error (s_max
 100), gradient-based objective scaling (max gradient 100), tol 1e-8,
 acceptable-point logic with the reference's options for mpc6/mpc8.
 
-PARITY UNPINNED at the solver boundary: there is no IPOPT output to compare
-with.  What pins this file: (1) the NLP functions are pinned to the reference's
-model code (tests/test_oracle_nlp.py); (2) KKT certificates on the ORIGINAL NLP
-and the independent known answers of SURVEY.md Appendix C
+PARITY at the solver boundary: IPOPT cannot run here; the one IPOPT output the
+reference repository holds -- its GIF of the demo9 closed loop, 83 chained solves
+whose Ts_opt the frame titles carry (tests/golden/reference_gif_demo9.json) --
+pins the C twin of this file on 42 consecutive steps with the reference's start
+and on 69 with the window as the first start (tests/test_reference_gif.py; where
+the runs part the solves end in different local optima).  Beyond that run parity is
+UNPINNED.  What else pins this file: (1) the NLP functions are pinned to the
+reference's model code (tests/test_oracle_nlp.py); (2) KKT certificates on the
+ORIGINAL NLP and the independent known answers of SURVEY.md Appendix C
 (tests/test_oracle_ipm.py).
 
 This dense version is the readable specification; oracle/obca_oracle.c is the

@@ -11,8 +11,8 @@ whose inequality constraints keep multiplicity N+1.
 
 Pinned by tests/test_oracle_nlp.py against tests/golden/nlp_eval.json, which was
 produced by running the reference's own model-building code on numbers
-(tests/golden/make_golden.py).  Solver parity with IPOPT itself is UNPINNED
-(casadi/IPOPT cannot run in the build container) -- see DESIGN.md.
+(tests/golden/make_golden.py).  Solver parity with IPOPT itself rests on ONE reference-held output (the demo9 GIF,
+tests/test_reference_gif.py) and is UNPINNED beyond it (casadi/IPOPT cannot run in the build container) -- see DESIGN.md.
 
 Variable layout (stage major):
     for k = 0..N:  p_k = (x, y, theta)      3
