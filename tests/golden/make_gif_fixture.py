@@ -125,6 +125,33 @@ def read_markers(im):
     return pts, float(1.0 / sx)
 
 
+GIF_DEMO1 = "/root/reference/images/OBCA_dynObs_demo1.gif"
+
+
+def read_demo1_markers():
+    """``images/OBCA_dynObs_demo1.gif``: a screen recording (2520 x 1080, no title, 147 frames) of the same animation for
+    demo1 -- which version of the code and which settings produced it is not recorded; its last frame shows the whole
+    closed-loop trajectory as orange markers.  Centres of the markers that stand alone, in map coordinates (axes box
+    0..39 m x 0..10 m)."""
+    im = Image.open(GIF_DEMO1)
+    im.seek(im.n_frames - 1)
+    rgb = np.asarray(im.convert("RGB")).astype(int)
+    dark = rgb.sum(2) < 150
+    cols, rows = np.where(dark.sum(0) > 300)[0], np.where(dark.sum(1) > 1200)[0]
+    x0p, x1p = cols[cols < 1000].mean(), cols[cols > 1000].mean()
+    y10p, y0p = rows.min() + 0.5, float(rows.max())
+    sx, sy = (x1p - x0p) / 39.0, (y0p - y10p) / 10.0
+    orange = (rgb[..., 0] > 200) & (abs(rgb[..., 1] - 165) < 45) & (rgb[..., 2] < 90)
+    lab, n = ndimage.label(orange)
+    pts = []
+    for i in range(1, n + 1):
+        ys, xs = np.where(lab == i)
+        if 300 <= len(ys) <= 420:
+            pts.append([round(float((xs.mean() - x0p) / sx), 3), round(float((y0p - ys.mean()) / sy), 3)])
+    pts.sort()
+    return pts, float(1.0 / sx)
+
+
 def main():
     im = Image.open(GIF)
     titles = read_titles(im)
@@ -142,6 +169,13 @@ def main():
     with open(os.path.join(HERE, "reference_gif_demo9.json"), "w") as f:
         json.dump(doc, f, indent=1)
     print("frames", len(titles), "last", titles[-1], "markers", len(markers))
+    pts, mpp = read_demo1_markers()
+    doc1 = {"source": "images/OBCA_dynObs_demo1.gif of the reference repository, last frame (screen recording; code version and "
+                      "settings of the run not recorded -- compared with the checked-in demo1 defaults)",
+            "markers_xy": pts, "metres_per_pixel": mpp}
+    with open(os.path.join(HERE, "reference_gif_demo1.json"), "w") as f:
+        json.dump(doc1, f, indent=1)
+    print("demo1 markers", len(pts))
 
 
 if __name__ == "__main__":
