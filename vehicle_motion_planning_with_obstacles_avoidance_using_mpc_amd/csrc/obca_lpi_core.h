@@ -1467,7 +1467,9 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
         ObcaOptsDev O3 = A.prm.opt;
         if (L.free_T && o.status == OBCA_STATUS_INFEASIBLE) O3.rho *= OBCA_RHO_ESCALATION;
         const Out o1 = o;
-        o = win1 ? solve_instance(L, S, in, O3) : solve_instance(L, S, in, O3, nullptr, OBCA_RESTART_MU, true);
+        // (window first: the second start is the cold start -- or the caller's optional warm start, as in the wave kernels)
+        o = win1 ? solve_instance(L, S, in, O3, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu)
+                 : solve_instance(L, S, in, O3, nullptr, OBCA_RESTART_MU, true);
         o.iters += o1.iters; o.nfact += o1.nfact;
     }
     if (A.warm_z != nullptr && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE)) {
