@@ -1447,29 +1447,30 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     const double dis = (S.xref[0 * N1 + L.N] - in.x0[0]) + (S.xref[1 * N1 + L.N] - in.x0[1]);
     in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
     const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
-    // obca_params.restart = 1 / 2 ("window first"): the two starts change places (csrc/obca_kernel.hip: obca_ipm_body)
+    // obca_params.restart = 1 / 2 ("window first"): the two starts change places (csrc/obca_kernel.hip: obca_ipm_body) -- the first
+    // two passes begin at the reference window, the last one at the cold start (or the caller's optional warm start)
     const bool win1 = A.prm.opt.start != 0;
-    Out o = win1 ? solve_instance(L, S, in, A.prm.opt, nullptr, OBCA_RESTART_MU, true)
-                 : solve_instance(L, S, in, A.prm.opt, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
+    const double* zw = warm ? A.warm_z + inst * (size_t)A.n_max : nullptr;
+    const double* z_first = win1 ? nullptr : zw;
+    const double* z_second = win1 ? zw : nullptr;
+    const double mu_first = win1 ? OBCA_RESTART_MU : A.warm_mu, mu_second = win1 ? A.warm_mu : OBCA_RESTART_MU;
+    Out o = solve_instance(L, S, in, A.prm.opt, z_first, mu_first, win1);
     if (o.status == OBCA_STATUS_INFEASIBLE && L.free_T) {
         // one penalty escalation for the free-time problem (the l1 penalty is exact only while rho exceeds the
         // multipliers): the same solve again with rho x 100 -- see csrc/obca_kernel.hip
         ObcaOptsDev O2 = A.prm.opt;
         O2.rho *= OBCA_RHO_ESCALATION;
         const Out o1 = o;
-        o = win1 ? solve_instance(L, S, in, O2, nullptr, OBCA_RESTART_MU, true)
-                 : solve_instance(L, S, in, O2, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu);
+        o = solve_instance(L, S, in, O2, z_first, mu_first, win1);
         o.iters += o1.iters; o.nfact += o1.nfact;
     }
     if (A.prm.opt.restart && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
-        // restart phase (every variant; oracle/ipm_dense.py:solve): the solve has not reached a feasible point from the
-        // reference's cold start -- once more from the reference window, barrier parameter OBCA_RESTART_MU
+        // restart phase (every variant; oracle/ipm_dense.py:solve): the solve has not reached a feasible point from its first
+        // start -- once more from the other one (default order: the reference window, barrier parameter OBCA_RESTART_MU)
         ObcaOptsDev O3 = A.prm.opt;
         if (L.free_T && o.status == OBCA_STATUS_INFEASIBLE) O3.rho *= OBCA_RHO_ESCALATION;
         const Out o1 = o;
-        // (window first: the second start is the cold start -- or the caller's optional warm start, as in the wave kernels)
-        o = win1 ? solve_instance(L, S, in, O3, warm ? A.warm_z + inst * (size_t)A.n_max : nullptr, A.warm_mu)
-                 : solve_instance(L, S, in, O3, nullptr, OBCA_RESTART_MU, true);
+        o = solve_instance(L, S, in, O3, z_second, mu_second, !win1);
         o.iters += o1.iters; o.nfact += o1.nfact;
     }
     if (A.warm_z != nullptr && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE)) {
