@@ -1,0 +1,66 @@
+"""dev tool (CPU only): where should a solve START?  Builds the host build of the structured core (tests/native) three ways
+and replays the reference's own demo9 run (tests/golden/reference_gif_demo9.json, tests/reference_gif.py) plus a sample of
+the headline batch:
+  zeros    the reference's all-zero start (src/obca.py:856) -- the default
+  window   obca_params.restart = 1: the reference window first
+  x0       -DOBCA_COLD_AT_X0: the all-zero start with every pose at x0, i.e. the iterate IPOPT's first full Newton step
+           reaches from zeros (linearised at v = 0 the dynamics read x_{k+1} = x_k)
+Prints, per start: consecutive GIF steps matched, steps run, mean iterations; on the C2 sample: converged share, mean
+iterations, instances ending at the optimum of the zeros start.       python tools/start_study.py [n_c2_instances]"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import c_oracle                                              # noqa: E402
+from tests import native_build, reference_gif                            # noqa: E402
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc   # noqa: E402
+
+
+def build(flag, out):
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-Wno-unknown-pragmas"] +
+                   ([flag] if flag else []) + [native_build.SRC, "-o", out], check=True)
+
+
+def load(path):
+    native_build._lib = None
+    native_build.OUT, native_build.DEPS = path, []
+    return native_build.load()
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    ref = np.asarray(reference_gif.fixture()["spend_time"][1:])
+    b = sc.make_batch(n, 5)
+    args = (4, 5, b["m"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"])
+    base = None
+    with tempfile.TemporaryDirectory() as tmp:
+        libs = {"zeros": (None, False), "window": (None, True), "x0": ("-DOBCA_COLD_AT_X0", False)}
+        for name, (flag, win) in libs.items():
+            path = os.path.join(tmp, "lib_%s.so" % ("x0" if flag else "plain"))
+            if not os.path.exists(path):
+                build(flag, path)
+            load(path)
+            s = native_build.LpiObca()
+            s.window_first = win
+            cum, _, cl = reference_gif.replay(s, 110)
+            k = min(len(cum), 83)
+            bad = np.where(np.abs(cum[:k] - ref[:k]) > reference_gif.TIME_TOL)[0]
+            o = native_build.lpi_solve(*args, params=c_oracle.default_params(restart=1 if win else 0))
+            ok = np.isin(o["status"], (0, 1))
+            if base is None:
+                base = o
+            same = ok & np.isin(base["status"], (0, 1)) & (np.abs(o["ts_opt"] - base["ts_opt"]) <= 1e-6 * np.maximum(1.0, np.abs(base["ts_opt"]))) & \
+                (np.abs(o["xopt"] - base["xopt"]).reshape(n, -1).max(1) <= 1e-5)
+            print("%-7s GIF: %2d consecutive steps of 83 (run: %d steps, goal %s, mean %.1f iterations) | C2 sample of %d: converged %.4f, "
+                  "mean %.1f iterations, %d at the optimum of the zeros start" %
+                  (name, int(bad[0]) if len(bad) else k, cl.k, cl.goal_reached(), np.mean([c["iters"] for c in s.calls]), n, ok.mean(),
+                   o["iters"].mean(), int(same.sum())), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1017,6 +1017,11 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
     } else {
         for (int t = 0; t < L.n; ++t) S.x[t] = 0.0;
         if (L.free_T) S.x[L.iT()] = 1.0;
+#ifdef OBCA_COLD_AT_X0              /* experiment (tools/start_study.py): the cold start with every pose at x0 -- where
+                                       IPOPT's first full Newton step lands from the all-zero start (the dynamics linearised at v = 0
+                                       read x_{k+1} = x_k, the initial condition x_0 = x0) */
+        if (!from_window) for (int k = 0; k <= L.N; ++k) for (int j = 0; j < 3; ++j) S.x[L.ip(k) + j] = in.x0[j];
+#endif
         if (from_window) {              // poses of the reference window, inputs by differences
             const int N1 = L.N + 1;
             for (int k = 0; k <= L.N; ++k)
