@@ -65,6 +65,16 @@ def test_window_first_replays_69_steps(fx, engine):
     assert d.max() <= reference_gif.MARKER_TOL, d.max()
 
 
+def test_window_first_run_is_as_long_as_the_references(fx):
+    """the GIF's file name carries N = 83 = k - 1 (src/closed_loop.py:441, src/draw.py:450): the reference reached the goal
+    after 84 closed-loop steps.  So does this build with the window as the first start (the default order needs 103)."""
+    s = native_build.LpiObca()
+    s.window_first = True
+    cum, xs, cl = reference_gif.replay(s, 120)
+    assert cl.goal_reached() and cl.k == 84 == fx["setting"]["frames"]
+    assert abs(cum[-2] - fx["spend_time"][-1]) < 0.5          # 129.72 s in the GIF's last frame (sum over 83 steps)
+
+
 def test_step_70_is_the_references_own_local_optimum(fx):
     """Where the window-first run leaves the GIF (step 70: Ts_opt 1.63 s here, 2.11 s in the GIF) this build's answer is the
     optimum an independent solver (SLSQP on the pinned model, from the window) reaches as well."""
