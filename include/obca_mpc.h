@@ -80,7 +80,8 @@ typedef struct obca_params {
                                                         IPOPT's optimum on 69 consecutive steps, the default order on 47
                                                         (then it settles in a worse local optimum), at a sixth of the
                                                         interior-point iterations
-                                                     2  the reference window only                                    */
+                                                     2  the reference window only
+                                                   (values above 2 are reserved; they are read as 1)                  */
 } obca_params;
 
 typedef struct obca_handle obca_handle;
