@@ -183,7 +183,7 @@ def config_c3(B, N=20, restart=0):
     return res
 
 
-def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66))):
+def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66)), window_first=False):
     """Row N3: the reference's open-loop free-time plan (closedLoop.mpc_openLoop_freeTime, src/closed_loop.py:113-120) as ONE
     instance through the drop-in `obca` class -- the only timing the reference publishes (src/simulation.py:230-231: N = 74
     136.69 s, N = 10 3.69 s, hardware unspecified).  Second call timed (the first allocates the handle's workspace)."""
@@ -195,6 +195,7 @@ def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66))):
            "reference_published_s": {"N=10": 3.69, "N=74": 136.69, "source": "src/simulation.py:230-231, hardware unspecified"}}
     for demo, N in cases:
         s = obca()
+        s.window_first = window_first
         cl = closedLoop(problemSetting(demo), solver=s)
         cl.N_free = N
         cl.mpc_openLoop_freeTime()
@@ -512,6 +513,8 @@ def main():
                 r = window_first_leg(solver, dv, out, B)
                 r["note"] = "obca_params.restart = 1: the reference window as the first start of every solve (NOT the default: the reference cold-starts, src/obca.py:856)"
                 r["config_c3"] = config_c3(B, restart=1)
+                ol = open_loop(window_first=True)
+                r["open_loop"] = {k: v for k, v in ol.items() if isinstance(v, dict) and "seconds" in v}
                 c5 = closed_loop_c5(args.closed_loop_rollouts, restart=1)
                 r["closed_loop"] = {k: c5[k] for k in ("value", "unit", "seconds", "converged_steps", "attempted_steps", "rollouts_to_step_cap", "rollouts_stopped_infeasible", "mean_ipm_iters") if k in c5}
                 return r
