@@ -79,7 +79,10 @@ typedef struct obca_params {
                                                         IPOPT solves, tests/test_reference_gif.py) this order returns
                                                         IPOPT's optimum on 69 consecutive steps, the default order on 47
                                                         (then it settles in a worse local optimum), at a sixth of the
-                                                        interior-point iterations
+                                                        interior-point iterations.  It needs a window that is itself a
+                                                        plausible trajectory: on the open-loop problem of demo1 at N = 10,
+                                                        whose start/goal-only reference runs through the box, it ends
+                                                        infeasible where the default order succeeds
                                                      2  the reference window only
                                                    (values above 2 are reserved; they are read as 1)                  */
 } obca_params;
