@@ -84,3 +84,24 @@ def test_penalty_escalation_solves_the_open_loop_problem():
     no_esc = native_build.lpi_solve(4, 10, c["m"], c["x0"][None], c["u0"][None], c["xref"][None], c["A"][None], c["b"][None],
                                     [c["Ts"]], None, c_oracle.default_params(rho=1e6))
     assert no_esc["status"][0] == 0 and no_esc["iters"][0] < c["iters"]         # the escalated pass alone
+
+
+def test_window_first_trusts_the_window():
+    """obca_params.restart = 1 is not a better default as it stands: the open-loop problem of demo1 at
+    N = 10 has a start/goal-only reference -- a straight line through the box -- and started from it the solve ends at an
+    infeasible stationary point, with the cold start as second start too (the escalated penalty stays), while the default order
+    finds the plan; where the window is a plausible trajectory (N = 20: twice as many points) both orders agree."""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
+    res = {}
+    for win in (False, True):
+        for N in (10, 20):
+            s = native_build.LpiObca()
+            s.window_first = win
+            cl = closedLoop(problemSetting("demo1"), solver=s)
+            cl.N_free = N
+            cl.mpc_openLoop_freeTime()
+            res[win, N] = (bool(cl.feas), float(cl.Ts_opt), s.calls[-1]["iters"])
+    assert res[False, 10][0] and res[False, 20][0] and res[True, 20][0]
+    assert not res[True, 10][0]
+    assert abs(res[True, 20][1] - res[False, 20][1]) < 1e-6 and res[True, 20][2] < res[False, 20][2]
