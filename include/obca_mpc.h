@@ -53,39 +53,50 @@ typedef struct obca_params {
     double uL[2], uU[2];               /* input box                                               */
     double ego[4];                     /* car footprint (closed_loop.py:63)                       */
     double dmin;                       /* clearance (closed_loop.py:64)                           */
-    /* interior-point options; <= 0 selects the default in brackets */
+    /* interior-point options; <= 0 selects the default in brackets.  The struct MUST be zero-initialised before its fields
+       are set (memset / = {0}): every option added later reads 0 as "default". */
     double tol;                        /* [1e-8]  IPOPT tol                                        */
     double rho;                        /* [1e4]   elastic (l1) penalty, unscaled objective units; a free-time solve
-                                                   that ends with elastic variables left is repeated once with
-                                                   rho x 100 (exact-penalty escalation)                      */
-    /* Recovery: a solve that ends without a feasible point -- status 2, -1, -2, -3 -- is repeated once from
-       the reference window xref (poses = xref, first pose x0; inputs by differences) instead of the reference's all-zero
-       start, inside the same launch ("restart phase"; rule and measurements: oracle/ipm_dense.py:solve).  The status,
-       iteration and factorisation counts returned are those of the whole sequence. */
+                                                   that ends with elastic variables left is repeated once from the same
+                                                   start with rho x 100 (exact-penalty escalation; the next start begins
+                                                   at rho again)                                            */
     double feas_tol;                   /* [1e-6]  largest elastic variable still called feasible   */
-    int32_t max_iter_free;             /* [3000]  IPOPT default, variant 4                         */
-    int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8                       */
+    int32_t max_iter_free;             /* [3000]  IPOPT default, variant 4: bounds EACH pass of a solve (see `patience`) */
+    int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8: likewise              */
     int32_t max_soc;                   /* [4]     IPOPT max_soc: second-order-correction trials after a rejected first
                                                    trial step; 0 = the default, negative = off              */
-    int32_t restart;                   /* [0]     the starts of a solve:
-                                                     0  (default) the reference's all-zero cold start (src/obca.py:856); the
-                                                        reference window as the second start (restart phase, see above)
-                                                    <0  the cold start only -- what a driver asks for where its own fallback
-                                                        follows, as obca_mpc8 follows a failed obca_mpc6 in the closed loop
-                                                        (src/closed_loop.py:393-398)
-                                                     1  "window first": the reference window as the first start, the cold
-                                                        start as the second.  On the one solver output the reference
-                                                        repository holds (its GIF of the demo9 closed loop: 83 chained
-                                                        IPOPT solves, tests/test_reference_gif.py) this order returns
-                                                        IPOPT's optimum on 69 consecutive steps, the default order on 47
-                                                        (then it settles in a worse local optimum), at a sixth of the
-                                                        interior-point iterations.  It needs a window that is itself a
-                                                        plausible trajectory: on the open-loop problem of demo1 at N = 10,
-                                                        whose start/goal-only reference runs through the box, it ends
-                                                        infeasible where the default order succeeds
-                                                     2  the reference window only
-                                                   (values above 2 are reserved; they are read as 1)                  */
+    /* The starts of a solve ("start ladder"; rule and measurements: oracle/ipm_dense.py:solve).  A solve
+       that ends without a feasible point -- status 2, -1, -2, -3 -- is repeated from the next start of the order, inside the
+       same launch, until one start ends feasible or the order is exhausted; status, iteration and factorisation counts
+       returned are those of the whole sequence, the iterate returned is the last pass's.  The three starts:
+         x0      every variable 0, Topt = 1 as the reference (src/obca.py:856), every pose at x0 -- the iterate IPOPT's first
+                 Newton step reaches from the reference's all-zero start (the initial condition and the dynamics linearised
+                 at v = 0 read x_k = x0); uses nothing but x0, like the reference's cold start
+         window  the poses of the reference window xref (first pose x0), inputs by differences clipped to their box
+         zeros   the reference's literal start: every variable 0, Topt = 1
+       No order makes a problem infeasible that another order solves: all three starts are tried in every order. */
+    int32_t start_order;               /* [OBCA_START_X0_FIRST] one of the OBCA_START_* constants below; anything else:
+                                                   OBCA_E_INVAL                                             */
+    int32_t single_start;              /* [0]     1 = only the first start of the order (with its penalty escalation) -- what a
+                                                   driver asks for where its own fallback follows, as obca_mpc8 follows a
+                                                   failed obca_mpc6 in the closed loop (src/closed_loop.py:393-398);
+                                                   other values than 0 / 1: OBCA_E_INVAL                    */
+    int32_t patience;                  /* [500 + 10 N]  while further starts remain, the FIRST start's passes are abandoned
+                                                   for the next start after this many iterations (solves converge far below
+                                                   it or crawl until max_iter); never above max_iter_*; with
+                                                   single_start = 1 only max_iter_* applies                 */
+    int32_t retry_iter;                /* [300 + 10 N]  iteration limit of every later start's passes; never above max_iter_* */
 } obca_params;
+
+/* obca_params.start_order */
+enum {
+    OBCA_START_X0_FIRST = 0,           /* x0 -> window -> zeros (default)                          */
+    OBCA_START_WINDOW_FIRST = 1,       /* window -> x0 -> zeros: fastest where the window is a plausible trajectory
+                                          (closed loops along an A* path)                          */
+    OBCA_START_ZEROS_FIRST = 2         /* zeros -> window -> x0: the reference's literal start first (the default of
+                                          obca_mpc 0.1)                                            */
+};
+
 
 typedef struct obca_handle obca_handle;
 

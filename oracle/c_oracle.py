@@ -17,7 +17,10 @@ class OracleParams(ctypes.Structure):
                [("dmin", ctypes.c_double), ("tol", ctypes.c_double), ("rho", ctypes.c_double),
                 ("feas_tol", ctypes.c_double), ("max_iter_free", ctypes.c_int), ("max_iter_fixed", ctypes.c_int),
                 ("max_soc", ctypes.c_int),          # 0 = IPOPT's default (4 second-order-correction trials), < 0 = off
-                ("restart", ctypes.c_int)]          # as obca_params.restart (include/obca_mpc.h): 0, < 0, 1 window first, 2 window only
+                # as obca_params (include/obca_mpc.h): the start ladder
+                ("start_order", ctypes.c_int), ("single_start", ctypes.c_int), ("patience", ctypes.c_int), ("retry_iter", ctypes.c_int)]
+
+START_ORDERS = {"x0": 0, "window": 1, "zeros": 2}
 
 
 _lib = None
@@ -61,7 +64,11 @@ def default_params(**kw):
     p.max_iter_free = int(kw.get("max_iter_free", 0))
     p.max_iter_fixed = int(kw.get("max_iter_fixed", 0))
     p.max_soc = int(kw.get("max_soc", 0))
-    p.restart = int(kw.get("restart", 0))
+    order = kw.get("start_order", 0)
+    p.start_order = int(START_ORDERS.get(order, order))
+    p.single_start = int(bool(kw.get("single_start", 0)))
+    p.patience = int(kw.get("patience", 0))
+    p.retry_iter = int(kw.get("retry_iter", 0))
     return p
 
 

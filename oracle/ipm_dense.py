@@ -125,20 +125,37 @@ def split_rows(p):
 
 
 RHO_ESCALATION = 100.0
-RESTART_MU = 1.0               # barrier parameter a restart begins with (csrc/obca_device.h: OBCA_RESTART_MU)
-def restart_max_iter(N):
-    """iteration limit of the restart pass (OBCA_RESTART_MAX_ITER: successful restarts take 16-117 iterations at N <= 20)"""
+RESTART_MU = 1.0               # barrier parameter the window start begins with (csrc/obca_device.h: OBCA_RESTART_MU)
+WINDOW_SPEED_FRAC = 0.9
+# the three starts of the ladder and the three orders (include/obca_mpc.h: start_order; csrc/obca_device.h: OBCA_START_KIND)
+KIND_X0, KIND_WINDOW, KIND_ZEROS = 0, 1, 2
+START_ORDERS = {0: (KIND_X0, KIND_WINDOW, KIND_ZEROS), 1: (KIND_WINDOW, KIND_X0, KIND_ZEROS), 2: (KIND_ZEROS, KIND_WINDOW, KIND_X0)}
+ORDER_NAMES = {"x0": 0, "window": 1, "zeros": 2}
+
+
+def retry_iter(N):
+    """iteration limit of the passes of every start after the first (csrc/obca_device.h: OBCA_RETRY_ITER: starts that succeed
+    there take 16-117 iterations at N <= 20)"""
     return 300 + 10 * N
 
 
 def patience(N):
-    """iteration limit of the passes before the restart, while the restart phase is on (csrc/obca_device.h: OBCA_PATIENCE)"""
+    """iteration limit of the first start's passes while further starts remain (csrc/obca_device.h: OBCA_PATIENCE)"""
     return 500 + 10 * N
-WINDOW_SPEED_FRAC = 0.9
+
+
+def x0_start(p):
+    """The default first start: the reference's cold start (all variables 0, Topt = 1; src/obca.py:856) with every pose at
+    x0 -- the iterate IPOPT's first full Newton step reaches from the all-zero start (linearised at v = 0 the dynamics read
+    x_{k+1} = x_k, the initial condition x_0 = x0).  Uses nothing but x0."""
+    z = p.start_point()
+    for k in range(p.N + 1):
+        z[p.ip(k):p.ip(k) + 3] = p.x0
+    return z
 
 
 def window_start(p):
-    """Start point of the restart phase: the poses of the reference window the call was given (first pose = x0), the
+    """The window start of the ladder: the poses of the reference window the call was given (first pose = x0), the
     inputs that drive from pose to pose (finite differences, clipped to the input box), for the free-time problem the
     time scale at which the window is driven at 0.9 of the speed bound (at least 1, at most max_Topt); lambda = mu = 0."""
     z = np.zeros(p.n)
@@ -162,42 +179,52 @@ def window_start(p):
 
 
 def solve(p, opts=None, trace=None):
-    """The elastic IPM from the reference's cold start, followed where needed by two recovery passes (same rule in
-    oracle/obca_oracle.c, csrc/obca_lpi_core.h and the wave kernels):
+    """The elastic IPM run through the START LADDER (same rule in oracle/obca_oracle.c, csrc/obca_lpi_core.h:run_instance and
+    the wave kernels; include/obca_mpc.h: start_order, single_start, patience, retry_iter):
 
+    * the starts of the order (default: x0 -> reference window -> zeros) are tried one after the other until one ends at a
+      feasible point.  IPOPT answers a solve that ends at an infeasible stationary point of its merit function, in a
+      line-search failure or at the iteration limit with its feasibility-restoration phase; measured on such instances the
+      restoration problem min ||c||_1 + zeta/2 ||D(x - x_R)||^2 started AT the stationary point x_R does not move (the l1
+      merit is at a local minimum there: a plan that dives under / through a moving box), whereas the same method from
+      another start the call's own inputs describe converges on 97 % of them.  A genuinely infeasible problem stays
+      infeasible.
     * penalty escalation (free-time problem only): the l1 penalty is exact only while rho exceeds the multipliers; if
       obca_mpc4 converges with elastic variables left (what "infeasible" looks like, but also what a too small rho looks
-      like -- seen on the open-loop problem of demo1, N = 10) the solve is repeated from the cold start with rho * 100;
-    * restart phase (every variant): a solve that still has not converged to a feasible point -- infeasible stationary
-      point of the penalty problem, line-search failure, iteration limit, numerical failure -- is repeated from
-      ``window_start``.  IPOPT answers such endings with its feasibility-restoration phase; measured on the failing
-      instances (tools/restoration_study.py) the restoration problem min ||c||_1 + zeta/2 ||D(x - x_R)||^2 started AT the
-      stationary point x_R does not move (the l1 merit is at a local minimum there: a plan that dives under / through a
-      moving box), whereas the same method started from the reference window -- the only other point the call's own
-      inputs describe -- with a ten times larger barrier parameter (IPOPT raises mu to max(mu, ||c||_inf) when it enters
-      restoration) converges on 97 % of them.  A genuinely infeasible problem stays infeasible."""
+      like -- seen on the open-loop problem of demo1, N = 10) the SAME start is repeated with rho * 100; the next start
+      begins at the base penalty again (measured on the reference's GIF run: with the raised penalty kept, the window and the
+      x0 start fail on a problem both solve at the base penalty).
+
+    opts: ``start_order`` 0 / 1 / 2 or "x0" / "window" / "zeros"; ``single_start``; ``patience``; ``retry_iter``;
+    ``no_escalation``.  With ``single_start`` a pass runs to ``max_iter``; otherwise the first start's passes stop after
+    ``patience`` iterations, the later starts' after ``retry_iter``."""
     opts = dict(opts or {})
-    # "window first" (obca_params.restart = 1 / 2, include/obca_mpc.h): the two starts change places
-    win1 = bool(opts.get("window_first"))
+    order = opts.get("start_order", 0)
+    kinds = START_ORDERS[ORDER_NAMES.get(order, order)]
+    if opts.get("single_start"):
+        kinds = kinds[:1]
     max_v = opts.get("max_iter", options_for(p.variant)["max_iter"])
     rho0 = opts.get("rho", DEFAULTS["rho"])
+    pat = opts.get("patience") or patience(p.N)
+    ret = opts.get("retry_iter") or retry_iter(p.N)
 
-    def run(from_window, rho):
-        if from_window:
-            return _solve_once(p, dict(opts, rho=rho, mu_init=RESTART_MU, max_iter=min(restart_max_iter(p.N), max_v)), trace,
-                               x_start=window_start(p))
-        o = dict(opts, rho=rho)
-        if not opts.get("no_restart"):
-            o["max_iter"] = min(max_v, patience(p.N))
-        return _solve_once(p, o, trace)
+    def run(s, kind, rho):
+        cap = max_v if len(kinds) == 1 else min(max_v, pat if s == 0 else ret)
+        o = dict(opts, rho=rho, max_iter=cap)
+        if kind == KIND_WINDOW:
+            return _solve_once(p, dict(o, mu_init=RESTART_MU), trace, x_start=window_start(p))
+        return _solve_once(p, o, trace, x_start=x0_start(p) if kind == KIND_X0 else None)
 
-    r = run(win1, rho0)
-    if r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation"):
-        r = _accumulate(run(win1, rho0 * RHO_ESCALATION), r)
-    if r.status not in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS) and not opts.get("no_restart"):
-        esc = p.variant == 4 and r.status == STATUS_INFEASIBLE and not opts.get("no_escalation")
-        r = _accumulate(run(not win1, rho0 * (RHO_ESCALATION if esc else 1.0)), r)
-        r.restarted = True
+    r = None
+    for s, kind in enumerate(kinds):
+        if r is not None and r.status in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS):
+            break
+        r_new = run(s, kind, rho0)
+        r = r_new if r is None else _accumulate(r_new, r)
+        if r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation"):
+            r = _accumulate(run(s, kind, rho0 * RHO_ESCALATION), r)
+        r.starts_used = s + 1
+    r.restarted = r.starts_used > 1
     return r
 
 

@@ -353,14 +353,17 @@ static void bk_solve(const double* A, int n, const int* piv, double* b) {
 /* ------------------------------------------------------------------------------------------------------ */
 typedef struct {
     double tol, rho, feas_tol;
-    int max_iter_free, max_iter_fixed, max_soc, restart;
+    int max_iter_free, max_iter_fixed, max_soc;
 } Opts;
 
 #define MU_INIT 0.1
 #define RESTART_MU 1.0            /* csrc/obca_device.h: OBCA_RESTART_MU */
 #define WINDOW_SPEED_FRAC 0.9
-#define RESTART_MAX_ITER(N) (300 + 10 * (N)) /* csrc/obca_device.h: OBCA_RESTART_MAX_ITER */
+#define RETRY_ITER(N) (300 + 10 * (N)) /* csrc/obca_device.h: OBCA_RETRY_ITER */
 #define PATIENCE(N) (500 + 10 * (N)) /* csrc/obca_device.h: OBCA_PATIENCE */
+/* the three starts of the ladder and the three orders (include/obca_mpc.h: start_order; csrc/obca_device.h: OBCA_START_KIND) */
+enum { KIND_X0 = 0, KIND_WINDOW = 1, KIND_ZEROS = 2 };
+static const int START_ORDERS[3][3] = {{KIND_X0, KIND_WINDOW, KIND_ZEROS}, {KIND_WINDOW, KIND_X0, KIND_ZEROS}, {KIND_ZEROS, KIND_WINDOW, KIND_X0}};
 #define KAPPA_MU 0.2
 #define THETA_MU 1.5
 #define KAPPA_EPS 10.0
@@ -387,8 +390,10 @@ typedef struct { double *s, *p, *n, *y, *zL, *zU, *zp, *zn, *lb, *ub, *w; int* e
 
 static double maxabs(const double* v, int n) { double m = 0; for (int i = 0; i < n; ++i) m = fmax(m, fabs(v[i])); return m; }
 
-/* from_window: restart phase -- start from the reference window (oracle/ipm_dense.py:window_start) with barrier parameter mu0 */
-static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double* ts, int* iters, double* info, int from_window, double mu0) {
+/* one pass of the ladder: start `kind` (oracle/ipm_dense.py: x0_start, window_start, or the reference's all-zero start) with barrier
+   parameter mu0 and at most iter_cap iterations (beside max_iter_*) */
+static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double* ts, int* iters, double* info, int kind, double mu0, int iter_cap) {
+    const int from_window = kind == KIND_WINDOW;
     const int n = p->n, mh = p->mh, me = p->me, na = p->naug, N = p->N;
     const int nk = n + mh + na;
     /* T rows carry multiplicity N+1 in the dense layout by being repeated (like oracle/obca_nlp.py) */
@@ -418,6 +423,7 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
     if (!filt_t) { free(mem); free(piv); free(eq); return ST_NUMERIC; }
     for (int i = 0; i < n; ++i) x[i] = 0;
     if (p->freeT) x[iT(p)] = 1.0;
+    if (kind == KIND_X0) for (int k = 0; k <= N; ++k) for (int j = 0; j < 3; ++j) x[ip(p, k) + j] = p->x0[j];
     if (from_window) {
         const int N1 = N + 1;
         for (int k = 0; k <= N; ++k) for (int j = 0; j < 3; ++j) x[ip(p, k) + j] = k == 0 ? p->x0[j] : p->xref[j * N1 + k];
@@ -468,8 +474,7 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
         double theta_max = 0, theta_min = 0, dw_last = 0, tau = fmax(TAU_MIN, 1 - mu), fprev = 0;
         int have_prev = 0, acc = 0;
         const int max_iter_v = p->freeT ? o->max_iter_free : o->max_iter_fixed;
-        const int max_iter_w = from_window ? RESTART_MAX_ITER(N) : (o->restart ? PATIENCE(N) : max_iter_v);
-        const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
+        const int max_iter = max_iter_v < iter_cap ? max_iter_v : iter_cap;
         const double acc_tol = p->freeT ? 1e-6 : 1e-8, acc_obj = p->freeT ? 1e20 : 1e-6;
         for (it = 0; it <= max_iter; ++it) {
             memset(Je, 0, sizeof(double) * (size_t)me * n);
@@ -791,7 +796,7 @@ typedef struct {
     double xL[2], xU[2], uL[2], uU[2], ego[4], dmin, tol, rho, feas_tol;
     int max_iter_free, max_iter_fixed;
     int max_soc;                            /* 0 = IPOPT's default (4), negative = off */
-    int restart;                            /* as obca_params.restart: 0 default, < 0 cold start only, 1 window first, 2 window only */
+    int start_order, single_start, patience, retry_iter;     /* as obca_params (include/obca_mpc.h) */
 } OracleParams;
 
 static void sym(double* d, const double* s, int k) { for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) d[k * a + b] = 0.5 * (s[k * a + b] + s[k * b + a]); }
@@ -845,30 +850,33 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         o.tol = prm->tol > 0 ? prm->tol : 1e-8; o.rho = prm->rho > 0 ? prm->rho : 1e4; o.feas_tol = prm->feas_tol > 0 ? prm->feas_tol : 1e-6;
         o.max_iter_free = prm->max_iter_free > 0 ? prm->max_iter_free : 3000; o.max_iter_fixed = prm->max_iter_fixed > 0 ? prm->max_iter_fixed : 1000;
         o.max_soc = prm->max_soc == 0 ? 4 : (prm->max_soc < 0 ? 0 : prm->max_soc);
-        /* prm->restart (include/obca_mpc.h): 0 cold start then window, < 0 cold start only, 1 window then cold start, 2 window only */
-        o.restart = !(prm->restart < 0 || prm->restart == 2);
-        const int win1 = prm->restart >= 1;
-        status[q] = solve_one(&p, &o, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, win1, win1 ? RESTART_MU : MU_INIT);
-        if (status[q] == ST_INFEASIBLE && p.variant == 4) {
-            /* one penalty escalation for the free-time problem (see oracle/ipm_dense.py:solve): cold start again, rho x 100 */
-            Opts o2 = o;
-            o2.rho = o.rho * 100.0;
-            const int it1 = iters[q];
-            const double nf1 = info ? info[(size_t)q * 4 + 3] : 0.0;
-            status[q] = solve_one(&p, &o2, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, win1, win1 ? RESTART_MU : MU_INIT);
-            iters[q] += it1;
-            if (info) info[(size_t)q * 4 + 3] += nf1;
+        /* the start ladder (oracle/ipm_dense.py:solve): the starts of the order until one ends at a feasible point; obca_mpc4 that
+           converged with elastic variables left repeats the same start once with rho x 100 (the next start begins at the base penalty) */
+        const int order = prm->start_order >= 0 && prm->start_order <= 2 ? prm->start_order : 0;
+        const int nstarts = prm->single_start ? 1 : 3;
+        const int max_iter_v = p.freeT ? o.max_iter_free : o.max_iter_fixed;
+        const int pat = prm->patience > 0 ? prm->patience : PATIENCE(N), ret = prm->retry_iter > 0 ? prm->retry_iter : RETRY_ITER(N);
+        double* xo = xopt + (size_t)q * 3 * (N + 1); double* uo = uopt + (size_t)q * 2 * N;
+        double* io = info ? info + (size_t)q * 4 : NULL;
+        int it_sum = 0;
+        double nf_sum = 0.0;
+        status[q] = ST_MAXITER;
+        for (int s = 0; s < nstarts; ++s) {
+            if (s > 0 && (status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) break;
+            const int kind = START_ORDERS[order][s];
+            const int cap = nstarts == 1 ? max_iter_v : (s == 0 ? pat : ret);
+            const double mu0 = kind == KIND_WINDOW ? RESTART_MU : MU_INIT;
+            status[q] = solve_one(&p, &o, xo, uo, ts_opt + q, iters + q, io, kind, mu0, cap);
+            it_sum += iters[q]; if (io) nf_sum += io[3];
+            if (status[q] == ST_INFEASIBLE && p.variant == 4) {
+                Opts o2 = o;
+                o2.rho = o.rho * 100.0;
+                status[q] = solve_one(&p, &o2, xo, uo, ts_opt + q, iters + q, io, kind, mu0, cap);
+                it_sum += iters[q]; if (io) nf_sum += io[3];
+            }
         }
-        if (o.restart && !(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
-            /* restart phase (oracle/ipm_dense.py:solve): once more from the reference window, mu = RESTART_MU */
-            Opts o3 = o;
-            if (p.variant == 4 && status[q] == ST_INFEASIBLE) o3.rho = o.rho * 100.0;
-            const int it1 = iters[q];
-            const double nf1 = info ? info[(size_t)q * 4 + 3] : 0.0;
-            status[q] = solve_one(&p, &o3, xopt + (size_t)q * 3 * (N + 1), uopt + (size_t)q * 2 * N, ts_opt + q, iters + q, info ? info + (size_t)q * 4 : NULL, !win1, win1 ? MU_INIT : RESTART_MU);
-            iters[q] += it1;
-            if (info) info[(size_t)q * 4 + 3] += nf1;
-        }
+        iters[q] = it_sum;
+        if (io) io[3] = nf_sum;
         free(Arep); free(brep);
     }
     return 0;

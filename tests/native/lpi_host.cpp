@@ -10,7 +10,7 @@ struct HostParams {            // same field order as oracle/c_oracle.py:OracleP
     double xL[2], xU[2], uL[2], uU[2], ego[4], dmin, tol, rho, feas_tol;
     int max_iter_free, max_iter_fixed;
     int max_soc;
-    int restart;               // 0 = default (on), negative = off
+    int start_order, single_start, patience, retry_iter;     // as obca_params (include/obca_mpc.h)
 };
 
 static void sym(double* d, const double* s, int k) {
@@ -49,7 +49,7 @@ extern "C" int lpi_host_solve_batch_warm(int N, int n_obs, const int* m, const i
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
     L.prm.opt.max_soc = p->max_soc == 0 ? OBCA_MAX_SOC : (p->max_soc < 0 ? 0 : p->max_soc);
-    L.prm.opt.restart = OBCA_OPT_RESTART(p->restart); L.prm.opt.start = OBCA_OPT_START(p->restart); L.prm.opt.pad_ = 0;
+    if (!obca_resolve_starts(&L.prm.opt, p->start_order, p->single_start, p->patience, p->retry_iter, N)) return -22;
     const lpi::Carve c = lpi::carve(N, n_obs, M, L.n_max, L.R_max);
     // The device lays the workspace out [element][instance] (stride = batch) so that a wave's accesses coalesce.  On the
     // host the same indexing is exercised with stride = B when B <= 8; larger batches give every OpenMP thread one

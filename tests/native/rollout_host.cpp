@@ -57,7 +57,7 @@ extern "C" int rollout_host_run(const obca_rollout_dims* d, const double* start,
             for (int i = 0; i < d->n_static; ++i) m[i] = d->m_static[i];
             for (int i = 0; i < g; ++i) m[d->n_static + i] = 4;
             HostParams h6 = *hp;
-            if (g > 0) h6.restart = h6.restart >= 1 ? 2 : -1;   // obca_mpc6: obca_mpc8 follows (csrc/obca_rollout.hip)
+            if (g > 0) h6.single_start = 1;   // obca_mpc6: obca_mpc8 follows (csrc/obca_rollout.hip)
             int rc = lpi_host_solve_batch_warm(g == 0 ? D.N : D.Nf, d->n_static + g, m, D.var[g], D.B, D.x0, D.u0, g == 0 ? D.xref : D.xref_fix, D.A[g], D.b[g], D.Ts, D.term,
                                                &h6, D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr,
                                                D.warm ? D.wz[g] : nullptr, D.warm ? D.wuse[g] : nullptr, warm_mu);

@@ -86,22 +86,22 @@ def test_penalty_escalation_solves_the_open_loop_problem():
     assert no_esc["status"][0] == 0 and no_esc["iters"][0] < c["iters"]         # the escalated pass alone
 
 
-def test_window_first_trusts_the_window():
-    """obca_params.restart = 1 is not a better default as it stands: the open-loop problem of demo1 at
-    N = 10 has a start/goal-only reference -- a straight line through the box -- and started from it the solve ends at an
-    infeasible stationary point, with the cold start as second start too (the escalated penalty stays), while the default order
-    finds the plan; where the window is a plausible trajectory (N = 20: twice as many points) both orders agree."""
+def test_open_loop_problem_is_feasible_in_every_start_order():
+    """The open-loop free-time problem of demo1 at N = 10 has a start/goal-only reference -- a straight line through the box.
+    Until obca_mpc 0.1 the window-first order ended infeasible on it (the raised penalty of the window pass was kept for the
+    cold start that followed); with the ladder every order finds the plan, and the same one: no order makes a feasible
+    reference call infeasible (include/obca_mpc.h: start_order)."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
     res = {}
-    for win in (False, True):
+    for order in ("x0", "window", "zeros"):
         for N in (10, 20):
             s = native_build.LpiObca()
-            s.window_first = win
+            s.start_order = order
             cl = closedLoop(problemSetting("demo1"), solver=s)
             cl.N_free = N
             cl.mpc_openLoop_freeTime()
-            res[win, N] = (bool(cl.feas), float(cl.Ts_opt), s.calls[-1]["iters"])
-    assert res[False, 10][0] and res[False, 20][0] and res[True, 20][0]
-    assert not res[True, 10][0]
-    assert abs(res[True, 20][1] - res[False, 20][1]) < 1e-6 and res[True, 20][2] < res[False, 20][2]
+            res[order, N] = (bool(cl.feas), float(cl.Ts_opt), s.calls[-1]["iters"])
+    assert all(v[0] for v in res.values()), res
+    for N in (10, 20):
+        assert max(abs(res[o, N][1] - res["x0", N][1]) for o in ("window", "zeros")) < 1e-6, res

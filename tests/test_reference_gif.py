@@ -3,7 +3,7 @@
 
 Frame k shows ``sum(Ts_opt[:k])`` to 0.01 s.  The mirror of ``closedLoop.closed_loop_mpc4`` driven by this build's solver
 must show the same numbers: every step's ``Ts_opt`` feeds the next step's obstacle prediction, start pose and input
-(src/closed_loop.py:349-432), so 47 chained solves -- 19 x obca_mpc4, the 11 x obca_mpc6 that dodge the moving box, 17 x
+(src/closed_loop.py:349-432), so 69 chained solves -- 19 x obca_mpc4, the 11 x obca_mpc6 that dodge the moving box, 39 x
 obca_mpc4 -- agreeing to the displayed digit means IPOPT and this solver returned the same optimum at every one of them."""
 import numpy as np
 import pytest
@@ -23,9 +23,9 @@ def test_fixture_shape(fx):
     assert ["%.2f" % v for v in t] == fx["spend_time_text"]          # %.2f as src/draw.py:380 prints it
 
 
-def _check(fx, engine, window_first, n, variants=None):
+def _check(fx, engine, order, n):
     s = native_build.LpiObca(engine)
-    s.window_first = window_first
+    s.start_order = order
     cum, xs, cl = reference_gif.replay(s, n)
     assert len(cum) == n
     ref = np.asarray(fx["spend_time"][1:n + 1])
@@ -38,46 +38,47 @@ def _check(fx, engine, window_first, n, variants=None):
     return xs, cl
 
 
-@pytest.mark.parametrize("engine,n", [("lpi", reference_gif.MATCHED_STEPS), ("oracle", reference_gif.MATCHED_STEPS_ORACLE)])
-def test_cpu_solvers_replay_the_reference_run(fx, engine, n):
-    """Default order of the starts (the reference's all-zero cold start first).  engine "oracle": the dense C oracle
-    (oracle/obca_oracle.c) -- this is what pins the ORACLE to the reference; engine "lpi": the structured core the kernels are
-    built from, compiled for the host.  47 / 42 chained solves show the reference's digits."""
-    xs, _ = _check(fx, engine, False, n)
-    # poses: every stand-alone marker of the GIF the run has passed (y < 41 m) has a pose of this run on it
-    m = np.asarray([p for p in fx["markers_xy"] if p[1] < 41.0])
-    assert len(m) >= 20
-    d = np.sqrt(((m[:, None, :] - xs[None, :, :2]) ** 2).sum(-1)).min(1)
-    assert d.max() <= reference_gif.MARKER_TOL, d.max()
-
-
 @pytest.mark.parametrize("engine", ["lpi", "oracle"])
-def test_window_first_replays_69_steps(fx, engine):
-    """obca_params.restart = 1 (the reference window as the first start, the cold start as the second): both CPU
-    implementations show the reference's digits for 69 consecutive steps -- through the corner where the default order parts --
-    at a sixth of the interior-point iterations."""
-    n = reference_gif.MATCHED_STEPS_WINDOW_FIRST
-    xs, cl = _check(fx, engine, True, n)
-    assert np.mean([c["iters"] for c in cl.obca_solver.calls]) < 40
+@pytest.mark.parametrize("order", ["x0", "window"])
+def test_cpu_solvers_replay_69_steps_of_the_reference_run(fx, engine, order):
+    """The default start ladder (x0 -> window -> zeros) and the window-first order: engine "oracle" is the dense C oracle
+    (oracle/obca_oracle.c) -- this is what pins the ORACLE to the reference; engine "lpi" the structured core the kernels are
+    built from, compiled for the host.  69 chained solves show the reference's digits."""
+    n = reference_gif.MATCHED[order][engine]
+    xs, cl = _check(fx, engine, order, n)
+    assert np.mean([c["iters"] for c in cl.obca_solver.calls]) < 45
+    # poses: every stand-alone marker of the GIF the run has passed has a pose of this run on it
     m = np.asarray([p for p in fx["markers_xy"] if p[1] < 53.3 and p[0] < 31.5])
     assert len(m) >= 40
     d = np.sqrt(((m[:, None, :] - xs[None, :, :2]) ** 2).sum(-1)).min(1)
     assert d.max() <= reference_gif.MARKER_TOL, d.max()
 
 
-def test_window_first_run_is_as_long_as_the_references(fx):
+@pytest.mark.parametrize("engine", ["lpi", "oracle"])
+def test_literal_zero_start_first_replays_the_first_phases(fx, engine):
+    """start_order "zeros" -- the reference's literal all-zero start first (src/obca.py:856), the default until obca_mpc 0.1: at
+    least 47 (dense oracle: 42) chained solves show the reference's digits, through the whole dodge of the moving box."""
+    n = reference_gif.MATCHED["zeros"][engine]
+    _check(fx, engine, "zeros", n)
+
+
+def test_run_is_as_long_as_the_references(fx):
     """the GIF's file name carries N = 83 = k - 1 (src/closed_loop.py:441, src/draw.py:450): the reference reached the goal
-    after 84 closed-loop steps.  So does this build with the window as the first start (the default order needs 103)."""
-    s = native_build.LpiObca()
-    s.window_first = True
-    cum, xs, cl = reference_gif.replay(s, 120)
+    after 84 closed-loop steps.  So does this build; after the one step where the two differ (70, see below) it keeps following
+    the GIF's clock at a constant distance."""
+    cum, xs, cl = reference_gif.replay(native_build.LpiObca(), 120)
     assert cl.goal_reached() and cl.k == 84 == fx["setting"]["frames"]
-    assert abs(cum[-2] - fx["spend_time"][-1]) < 0.5          # 129.72 s in the GIF's last frame (sum over 83 steps)
+    ref = np.asarray(fx["spend_time"])
+    err = np.abs(cum[:reference_gif.GIF_STEPS] - ref[1:])
+    assert err.max() < 0.5 and abs(cum[reference_gif.GIF_STEPS - 1] - ref[-1]) < 0.35          # 129.72 s in the GIF's last frame
+    steps, steps_ref = np.diff(cum[:reference_gif.GIF_STEPS]), np.diff(ref[1:])
+    assert np.abs(steps - steps_ref)[70:].max() < 0.04       # every later Ts_opt within a title's rounding of the GIF's
 
 
 def test_step_70_is_the_references_own_local_optimum(fx):
-    """Where the window-first run leaves the GIF (step 70: Ts_opt 1.63 s here, 2.11 s in the GIF) this build's answer is the
-    optimum an independent solver (SLSQP on the pinned model, from the window) reaches as well."""
+    """Where the run leaves the GIF (step 70: Ts_opt 1.63 s here, 2.11 s in the GIF) this build's answer is the optimum an
+    independent solver (SLSQP on the pinned model, from the window) reaches as well -- it is the reference's IPOPT run that
+    settled in a worse local optimum at this step, not this build's."""
     from oracle.obca_nlp import Problem
     from tests import independent
 
@@ -86,10 +87,11 @@ def test_step_70_is_the_references_own_local_optimum(fx):
             self.args4 = a
             return super().obca_mpc4(*a)
     s = Rec()
-    s.window_first = True
-    cum, _, cl = reference_gif.replay(s, 70)
+    n = reference_gif.MATCHED["x0"]["lpi"]
+    cum, _, cl = reference_gif.replay(s, n + 1)
     ref = np.asarray(fx["spend_time"])
-    assert abs((cum[69] - cum[68]) - (ref[70] - ref[69])) > 0.3
+    assert np.abs(cum[:n] - ref[1:n + 1]).max() <= reference_gif.TIME_TOL
+    assert (ref[n + 1] - ref[n]) - (cum[n] - cum[n - 1]) > 0.3          # the GIF's step is the LONGER one
     a = s.args4
     p = Problem.from_reference_args(4, *a[:18])
     r = independent.slsqp(p, independent.trajectory_start(p, p.xref))
@@ -97,19 +99,9 @@ def test_step_70_is_the_references_own_local_optimum(fx):
     assert abs(r["z"][p.iT()] * p.Ts - cl.T_closed[-1]) <= 1e-4
     z = p.pack(cl.xOpt, cl.uOpt, np.zeros((p.M, p.N + 1)), np.zeros((4 * p.nObs, p.N + 1)), cl.T_closed[-1] / p.Ts)
     assert abs(p.objective(z) - r["f"]) <= 1e-5 * max(1.0, abs(r["f"]))
-
-
-def test_where_the_runs_part(fx):
-    """Documented, not hidden: at step 48 (pose (11.43, 48.75, 0.89), the left turn round the block corner at (13, 49)) the
-    reference's IPOPT returned Ts_opt = 1.44 s (objective 58.71, which SLSQP reaches too), this solver from the cold start
-    another, worse stationary point (2.01 s, objective 84.46); from there on the closed loops differ.  The test keeps the figure
-    honest: if a change moves the first differing step, MATCHED_STEPS must follow."""
-    n = reference_gif.MATCHED_STEPS
-    cum, _, _ = reference_gif.replay(native_build.LpiObca(), n + 1)
-    ref = np.asarray(fx["spend_time"][1:n + 2])
-    err = np.abs(cum - ref)
-    assert err[:n].max() <= reference_gif.TIME_TOL
-    assert err[n] > 0.1
+    # the GIF's Ts_opt is feasible for the same problem but costs more: the time term alone, (N + 1)(10 T + T^2), is larger
+    T_here, T_gif = cl.T_closed[-1] / p.Ts, (ref[n + 1] - ref[n]) / p.Ts
+    assert (p.N + 1) * (10 * T_gif + T_gif ** 2) > p.objective(z)
 
 
 def test_demo1_recording_first_twelve_steps():

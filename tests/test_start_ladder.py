@@ -1,0 +1,161 @@
+"""The start ladder (oracle/ipm_dense.py:solve, include/obca_mpc.h: start_order / single_start / patience / retry_iter) on the
+CPU: numpy specification, C oracle and the structured core (csrc/obca_lpi_core.h, the code the lane kernel runs) apply the same
+rule and reach the same points.  Anchor: SURVEY Appendix C's "mpc6 witness" (demo1, moving box advanced 8 steps) -- the first
+start ends at an infeasible stationary point, a feasible plan with f = 0.029735 exists; the survey's criterion is feas = True
+with f <= 0.02974."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle, ipm_dense
+from tests import kkt_check, native_build
+from tests.test_oracle_nlp import build
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import pack_reference_call
+
+F_WITNESS = 0.02974
+
+
+def _packed(case, **extra):
+    a = case["inputs"]
+    m, x0, u0, xr, A, b, ts, term = pack_reference_call(case["variant"], a["Ts"], a["N"], a["x0"], a["xref"], a["nObs"], a["vObs"],
+                                                        a["AObs"], a["bObs"], a["u0"], a.get("terminal_set"))
+    R = [np.array(r) for r in a["R"]]
+    kw = dict(xL=a["xL"][:2], xU=a["xU"][:2], uL=a["uL"], uU=a["uU"], ego=a["ego"], dmin=a["dmin"], **extra)
+    kw.update(dict(Qf=a["Q"], Pf=a["P"], R1f=R[0], R2f=R[1]) if case["variant"] == 4 else dict(Qx=a["Q"], Px=a["P"], R1x=R[0], R2x=R[1]))
+    return (case["variant"], a["N"], m, x0[None], u0[None], xr[None], A[None], b[None], [ts], term[None], c_oracle.default_params(**kw))
+
+
+@pytest.mark.parametrize("order", ["x0", "window", "zeros"])
+def test_mpc6_witness_is_met_by_all_three_cpu_implementations_in_every_order(nlp_golden, order):
+    case = [c for c in nlp_golden if c["name"] == "demo1_dyn_mpc6"][0]
+    p = build(case)
+    r = ipm_dense.solve(p, dict(start_order=order))
+    assert r.feas and r.f <= F_WITNESS + 1e-6
+    assert r.restarted == (order != "window")                      # x0 and zeros end under the box; the window start finds the plan
+    cert = ipm_dense.kkt_certificate(p, r)
+    assert cert["primal"] < 1e-8 and cert["stationarity"] < 1e-6 and cert["complementarity"] < 1e-6
+    assert r.xopt[1].max() > 7.9                                   # passes ABOVE the moving box (the witness's class)
+    args = _packed(case, start_order=order)
+    c = c_oracle.solve_batch(*args)
+    g = native_build.lpi_solve(*args)
+    for o in (c, g):
+        assert o["status"][0] == 0 and o["info"][0, 0] <= F_WITNESS + 1e-6
+        np.testing.assert_allclose(o["xopt"][0], r.xopt, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(o["uopt"][0], r.uopt, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("order", ["x0", "zeros"])
+def test_single_start_ends_where_the_first_start_ends(nlp_golden, order):
+    """obca_params.single_start = 1: the first start of the order alone -- on the witness it ends at the infeasible stationary
+    point (status 2), which is what a driver with its own fallback (obca_mpc8 after obca_mpc6) asks for"""
+    case = [c for c in nlp_golden if c["name"] == "demo1_dyn_mpc6"][0]
+    r = ipm_dense.solve(build(case), dict(start_order=order, single_start=True))
+    assert r.status == ipm_dense.STATUS_INFEASIBLE and not r.restarted
+    args = _packed(case, start_order=order, single_start=1)
+    assert c_oracle.solve_batch(*args)["status"][0] == 2
+    assert native_build.lpi_solve(*args)["status"][0] == 2
+
+
+@pytest.mark.parametrize("order", ["x0", "window", "zeros"])
+def test_a_genuinely_infeasible_problem_stays_infeasible(nlp_golden, order):
+    """demo1 at N = 5 (the terminal pose collides): all three starts run, each with its penalty escalation,
+    feas stays False -- and the whole sequence is the same in the three implementations, iterate for iterate"""
+    case = [c for c in nlp_golden if c["name"] == "demo1_N5_mpc4_step0"][0]
+    r = ipm_dense.solve(build(case), dict(start_order=order))
+    assert r.status == ipm_dense.STATUS_INFEASIBLE and r.starts_used == 3 and r.elastic > 1e-3
+    args = _packed(case, start_order=order)
+    c, g = c_oracle.solve_batch(*args), native_build.lpi_solve(*args)
+    assert c["status"][0] == 2 and g["status"][0] == 2
+    assert c["iters"][0] == r.iters == g["iters"][0]
+    singles = [native_build.lpi_solve(*_packed(case, start_order=o, single_start=1))["iters"][0] for o in ("x0", "window", "zeros")]
+    assert sum(singles) == r.iters                                 # the ladder is the three starts one after the other
+
+
+def test_iteration_limits_of_the_ladder(nlp_golden):
+    """include/obca_mpc.h: max_iter_* bounds each pass; while further starts remain the first start's passes stop after
+    `patience`, the later ones after `retry_iter`; with single_start only max_iter_* applies (the advisor's round-3 finding:
+    the caps must not override the caller's max_iter silently).  demo1_dyn_mpc6: the x0 start needs 59 iterations to reach its
+    infeasible stationary point, the window start 49 to the plan."""
+    case = [c for c in nlp_golden if c["name"] == "demo1_dyn_mpc6"][0]
+    for engine in (c_oracle.solve_batch, native_build.lpi_solve):
+        it0 = engine(*_packed(case, single_start=1))["iters"][0]               # the x0 start alone, to its end
+        o = engine(*_packed(case, patience=20))                                  # first start abandoned after 20 iterations
+        assert o["status"][0] == 0 and 20 < o["iters"][0] < it0 + 49
+        o = engine(*_packed(case, patience=20, retry_iter=10))                   # ... and the later starts after 10 each
+        assert o["status"][0] == -1 and o["iters"][0] <= 20 + 10 + 10 + 3
+        o = engine(*_packed(case, single_start=1, patience=20, max_iter_fixed=2000))
+        assert o["status"][0] == 2 and o["iters"][0] == it0                      # single start: patience does not apply
+        o = engine(*_packed(case, single_start=1, max_iter_fixed=30))
+        assert o["status"][0] == -1 and o["iters"][0] <= 31                      # ... max_iter does
+
+
+def test_patience_above_its_default_is_honoured():
+    """A first start that crawls: step 51 of the reference's demo9 run replayed with the literal zero start first (tests/
+    reference_gif.py) -- the zero start converges to an infeasible stationary point, its repetition with the raised penalty never
+    converges, the window start solves the problem in 28 iterations.  The default patience (500 + 10 N = 550) hands over after 550
+    iterations of that pass; a caller who sets patience = 2000 gets 2000."""
+    from tests import reference_gif
+    s = native_build.LpiObca()
+    s.start_order = "zeros"
+    reference_gif.replay(s, 51)
+    c = s.calls[50]
+    assert c["status"] == 0 and 550 < c["iters"] < 550 + 350
+    arrs = (4, 5, c["m"], c["x0"][None], c["u0"][None], c["xref"][None], c["A"][None], c["b"][None], [c["Ts"]], c["term"][None])
+    kw = dict(xL=[0, 0], xU=[40, 60], Qf=0.5 * np.eye(3), Pf=0.5 * np.eye(3), start_order="zeros")
+    base = native_build.lpi_solve(*arrs, c_oracle.default_params(**kw))
+    assert base["status"][0] == 0 and base["iters"][0] == c["iters"]
+    long = native_build.lpi_solve(*arrs, c_oracle.default_params(patience=2000, **kw))
+    assert long["status"][0] == 0 and long["iters"][0] == c["iters"] - 550 + 2000
+    np.testing.assert_allclose(long["xopt"], base["xopt"], atol=1e-9)
+    capped = native_build.lpi_solve(*arrs, c_oracle.default_params(patience=2000, max_iter_free=300, **kw))
+    assert capped["iters"][0] < c["iters"]                                      # never above max_iter_free
+
+
+@pytest.mark.parametrize("name", ["demo1_dyn_mpc6", "demo9_N5_mpc4_step0", "slanted_asym_mpc4"])
+def test_window_start_point(nlp_golden, name):
+    p = build([c for c in nlp_golden if c["name"] == name][0])
+    z = ipm_dense.window_start(p)
+    xs, us = p.unpack_xu(z)
+    assert np.array_equal(xs[:, 0], p.x0) and np.array_equal(xs[:, 1:], p.xref[:, 1:])
+    assert (us[0] >= p.uL[0]).all() and (us[0] <= p.uU[0]).all() and (us[1] >= p.uL[1]).all() and (us[1] <= p.uU[1]).all()
+    if p.variant == 4:
+        T = z[p.iT()]
+        assert 1.0 <= T <= max(1.0, p.Tmax)
+        seg = np.hypot(*np.diff(xs[:2], axis=1))
+        assert T == pytest.approx(min(max(1.0, seg.sum() / (p.N * 0.9 * p.uU[0] * p.Ts)), max(1.0, p.Tmax)))
+    lam_mu = np.ones(p.n, bool)
+    for k in range(p.N + 1):
+        lam_mu[p.ip(k):p.ip(k) + (5 if k < p.N else 3)] = False
+    if p.variant == 4:
+        lam_mu[p.iT()] = False
+    assert not z[lam_mu].any()
+
+
+def test_x0_start_point(nlp_golden):
+    p = build([c for c in nlp_golden if c["name"] == "demo9_N5_mpc4_step0"][0])
+    z = ipm_dense.x0_start(p)
+    xs, us = p.unpack_xu(z)
+    assert np.array_equal(xs, np.repeat(np.asarray(p.x0, float)[:, None], p.N + 1, 1)) and not us.any() and z[p.iT()] == 1.0
+    z0 = p.start_point()                                           # the reference's literal start: zeros, Topt = 1 (src/obca.py:856)
+    diff = np.flatnonzero(z != z0)
+    assert set(diff) <= {p.ip(k) + j for k in range(p.N + 1) for j in range(3)}
+
+
+def test_c3_gated_batch_with_the_ladder_structured_core_against_dense_oracle():
+    """config 3's fixed-time half at N = 8 (the dense oracle's reach): 32 instances through the structured core and the
+    dense C oracle.  Where the first start fails both go on to the next; verdicts agree, every answer of the core is certified
+    on the reference-pinned model, and the ladder is what lifts the share of converged instances."""
+    N, B = 8, 32
+    b = sc.make_batch_c3(B, N, gated=True)
+    args = (b["variant"], N, b["m"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"])
+    cold = native_build.lpi_solve(*args, params=c_oracle.default_params(single_start=1))
+    got = native_build.lpi_solve(*args, cert=True)
+    ref = c_oracle.solve_batch(*args, threads=8)
+    ok_cold, ok = np.isin(cold["status"], (0, 1)), np.isin(got["status"], (0, 1))
+    assert (ok | ~ok_cold).all()                                   # nothing that converged cold is lost
+    assert ok.sum() > ok_cold.sum() and ok.mean() >= 0.9
+    assert (np.isin(ref["status"], (0, 1)) != ok).sum() <= 1       # long non-convex runs: one verdict may flip with roundoff
+    for i in np.flatnonzero(ok):
+        c = kkt_check.certificate(kkt_check.problem_of(b, i, N), got["z"][i], got["y"][i])
+        for k in ("stationarity", "primal", "dual_sign", "complementarity"):
+            assert c[k] <= 1e-6, (i, k, c)

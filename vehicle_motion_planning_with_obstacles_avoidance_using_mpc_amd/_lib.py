@@ -30,7 +30,13 @@ class ObcaParams(ctypes.Structure):
                 ("ego", ctypes.c_double * 4), ("dmin", ctypes.c_double),
                 ("tol", ctypes.c_double), ("rho", ctypes.c_double), ("feas_tol", ctypes.c_double),
                 ("max_iter_free", ctypes.c_int32), ("max_iter_fixed", ctypes.c_int32), ("max_soc", ctypes.c_int32),
-                ("restart", ctypes.c_int32)]
+                ("start_order", ctypes.c_int32), ("single_start", ctypes.c_int32), ("patience", ctypes.c_int32),
+                ("retry_iter", ctypes.c_int32)]
+
+
+# obca_params.start_order (include/obca_mpc.h)
+START_X0_FIRST, START_WINDOW_FIRST, START_ZEROS_FIRST = 0, 1, 2
+START_ORDERS = {"x0": START_X0_FIRST, "window": START_WINDOW_FIRST, "zeros": START_ZEROS_FIRST}
 
 
 class ObcaRolloutDims(ctypes.Structure):

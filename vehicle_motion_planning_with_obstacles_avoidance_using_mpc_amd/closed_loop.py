@@ -27,11 +27,16 @@ class closedLoop:
             from .obca import obca
             solver = obca()
         self.obca_solver = solver
-        # this driver answers a failed obca_mpc6 with obca_mpc8 itself (step(), mpc_openLoop_fixTime), so it asks the solver
-        # object -- where it offers the switch -- to skip the restart phase of obca_mpc6 (include/obca_mpc.h: restart); the
-        # device-resident rollouts do the same (csrc/obca_rollout.hip)
-        if hasattr(solver, "restart_obca_mpc6"):
-            solver.restart_obca_mpc6 = False
+        # this driver answers a failed obca_mpc6 with obca_mpc8 itself (step(), mpc_openLoop_fixTime), so it asks obca_mpc6 --
+        # where the solver object offers the keyword -- for the first start of the ladder only (include/obca_mpc.h:
+        # single_start); the device-resident rollouts do the same (csrc/obca_rollout.hip).  Per call: the injected solver
+        # object is not changed, a bare obca_mpc6 call on it still runs the whole ladder.
+        import inspect
+        try:
+            has_kw = "single_start" in inspect.signature(solver.obca_mpc6).parameters
+        except (AttributeError, TypeError, ValueError):
+            has_kw = False
+        self._mpc6_kw = {"single_start": True} if has_kw else {}
         st = self.setting
         self.path_solver = a_star(st.org_gridMap, (st.startPose[1], st.startPose[0]), (st.goalPose[1], st.goalPose[0]))
         # constants of src/closed_loop.py:32-101
@@ -84,7 +89,7 @@ class closedLoop:
         self.fixtime = 1
         args = (self.Ts, self.P_fix, self.Q_fix, self.R_fix, self.N_fix, self.x0, self.xL, self.xU, self.uL, self.uU,
                 self.xref, self.nObs, self.vObs, self.AObs, self.bObs, self.dmin, self.ego, self.u0, self.uOpt)
-        self.xOpt, self.uOpt, self.feas, self.Ts_opt = self.obca_solver.obca_mpc6(*args, self.terminal_set)
+        self.xOpt, self.uOpt, self.feas, self.Ts_opt = self.obca_solver.obca_mpc6(*args, self.terminal_set, **self._mpc6_kw)
         if self.feas == False:  # noqa: E712  (same test as the reference)
             self.xOpt, self.uOpt, self.feas, self.Ts_opt = self.obca_solver.obca_mpc8(*args)
 
@@ -141,7 +146,7 @@ class closedLoop:
         if variant == 4:
             res = self.obca_solver.obca_mpc4(*args)
         else:
-            res = self.obca_solver.obca_mpc6(*args)
+            res = self.obca_solver.obca_mpc6(*args, **self._mpc6_kw)
             if res[2] == False:  # noqa: E712
                 res = self.obca_solver.obca_mpc8(*args[:-1])
         return self.finish_step(res)
@@ -196,6 +201,14 @@ class closedLoop:
             if type == "startGoal_only":
                 ref_x[:, 0] = x0[:3]
                 ref_x[:, 1:] = np.asarray(xF[:3], float)[:, None]
+            elif type == "startGoal_smooth":
+                # src/closed_loop.py:545-553: N + 1 points on the straight line start -> goal, heading of every point = direction
+                # to its successor (last heading repeated)
+                steps = np.arange(N + 1)
+                ref_x[0] = ((xF[0] - x0[0]) / N) * steps + x0[0]
+                ref_x[1] = ((xF[1] - x0[1]) / N) * steps + x0[1]
+                ref_x[2, :N] = np.arctan2(np.diff(ref_x[1]), np.diff(ref_x[0]))
+                ref_x[2, N] = ref_x[2, N - 1]
             elif type == "A_star" and getattr(self.setting, "ref_path", None) is not None:
                 ref_x = np.array(self.setting.ref_path, dtype=float)      # Monte-Carlo worlds carry their own path
             elif type == "A_star":
@@ -205,6 +218,8 @@ class closedLoop:
                 route = self.path_solver.solve(st.org_gridMap, start, goal)
                 path = self.path_solver.create_reference_path(self.path_solver.rebuild_path(route))
                 ref_x = np.asarray(path).T
+            elif type != "":
+                raise ValueError("update_path: unknown reference type %r" % (type,))
             return ref_x
         # allAviable == 1: resample the current reference to N_fix segments, recompute yaw, rescale the step
         ratio = int(self.N_fix / self.N_free)
@@ -254,7 +269,7 @@ class BatchClosedLoop:
         from .solver import BatchSolver, SolverParams
         self._BatchSolver, self._SolverParams = BatchSolver, SolverParams
         self.rollouts = list(rollouts)
-        self.window_first = bool((params_kw or {}).get("window_first"))      # include/obca_mpc.h: restart = 1 / 2
+        self.start_order = (params_kw or {}).get("start_order", 0)           # include/obca_mpc.h: start_order
         self.solvers = {}
         self.steps_solved = 0
         self.steps_converged = 0
@@ -275,11 +290,8 @@ class BatchClosedLoop:
         a0 = calls[0][2]
         free = calls[0][1] == 4
         kw = dict(xL=a0[6], xU=a0[7], uL=a0[8], uU=a0[9], ego=a0[16], dmin=a0[15])
-        win1 = self.window_first
-        if calls[0][1] == 6:
-            kw["restart"] = 2 if win1 else -1   # obca_mpc8 follows a failed obca_mpc6 (step()): one start only
-        elif win1:
-            kw["restart"] = 1
+        kw["start_order"] = self.start_order
+        kw["single_start"] = calls[0][1] == 6   # obca_mpc8 follows a failed obca_mpc6 (step()): the first start only
         prm = self._SolverParams(Q_free=a0[2], R_free=a0[3], P_free=a0[1], **kw) if free else \
             self._SolverParams(Q_fix=a0[2], R_fix=a0[3], P_fix=a0[1], **kw)
         st = lambda j: np.stack([p[j] for p in packed])

@@ -289,7 +289,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
     L.prm.opt.max_soc = p->max_soc == 0 ? OBCA_MAX_SOC : (p->max_soc < 0 ? 0 : p->max_soc);
-    L.prm.opt.restart = OBCA_OPT_RESTART(p->restart); L.prm.opt.start = OBCA_OPT_START(p->restart); L.prm.opt.pad_ = 0;
+    if (!obca_resolve_starts(&L.prm.opt, p->start_order, p->single_start, p->patience, p->retry_iter, h->dims.N)) return OBCA_E_INVAL;
     if (lds_bytes) *lds_bytes = h->lds_bytes;
     if (wave_ok) *wave_ok = h->wave_ok ? 1 : 0;
     return OBCA_OK;
@@ -334,7 +334,7 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw || !lane) {
-        // the kernels run the recovery passes (penalty escalation, restart phase) themselves, from their own copy of the descriptor
+        // the kernels run the further passes of the start ladder (penalty escalation, next starts) themselves, from their own copy of the descriptor
         ObcaLaunch L2 = L;
         if (mw)
             hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
@@ -371,4 +371,4 @@ extern "C" const char* obca_strerror(int code) {
     }
 }
 
-extern "C" const char* obca_version(void) { return "obca_mpc 0.1 (gfx950)"; }
+extern "C" const char* obca_version(void) { return "obca_mpc 0.2 (gfx950)"; }

@@ -41,26 +41,38 @@
 #define OBCA_KAPPA_SOC 0.99
 #define OBCA_MAX_SOC 4
 #define OBCA_RHO_ESCALATION 100.0   /* obca_mpc4 only: one retry with rho x 100 when elastic variables remain */
-/* Restart phase (every variant; rule and measurements in oracle/ipm_dense.py:solve): a solve that ended without a feasible
-   point is repeated ONCE from the reference window -- poses = xref (first pose x0), inputs by differences clipped to their
-   box, free-time problem: the time scale at which the window is driven at this fraction of the speed bound -- with a
-   larger initial barrier parameter (IPOPT's restoration phase likewise raises mu to max(mu, ||c||_inf)). */
+/* Start ladder (every variant; rule and measurements in oracle/ipm_dense.py:solve, include/obca_mpc.h: start_order): a solve that
+   ended without a feasible point is repeated from the next start of the order.  The three starts:
+     OBCA_KIND_X0      all variables 0, Topt = 1, every pose at x0 (IPOPT's first Newton iterate from the reference's start)
+     OBCA_KIND_WINDOW  poses = xref (first pose x0), inputs by differences clipped to their box, free-time problem: the time
+                       scale at which the window is driven at OBCA_WINDOW_SPEED_FRAC of the speed bound -- with a larger initial
+                       barrier parameter (IPOPT's restoration phase likewise raises mu to max(mu, ||c||_inf))
+     OBCA_KIND_ZEROS   the reference's literal start (src/obca.py:856): all variables 0, Topt = 1 */
+#define OBCA_KIND_X0 0
+#define OBCA_KIND_WINDOW 1
+#define OBCA_KIND_ZEROS 2
+/* kind of start s = 0, 1, 2 of obca_params.start_order o (two bits per start): x0/window/zeros, window/x0/zeros, zeros/window/x0 */
+#define OBCA_START_KIND(o, s) (((((o) == 1) ? 0x21 : ((o) == 2) ? 0x06 : 0x24) >> (2 * (s))) & 3)
+/* the caller's optional warm start (obca_set_warm_start) takes the place of the first COLD start of the order */
+#define OBCA_WARM_KIND(o) ((o) == 2 ? OBCA_KIND_ZEROS : OBCA_KIND_X0)
 #define OBCA_RESTART_MU 1.0
-/* Patience of the passes BEFORE the restart (only while the restart phase is on): a pass that has not converged after this many
-   iterations is abandoned for the restart.  Measured (tools/restart_study.py): solves either converge well below
-   it -- N = 5: <= 301 iterations, N = 20: <= 389, N = 74: ~500 per pass -- or crawl at an indefinite point with delta_w ~ 1e3
-   until max_iter (3000 for obca_mpc4: 0.27 s on one wavefront), nothing in between. */
+/* Iteration limits of the passes while further starts remain (obca_params.patience / retry_iter; <= 0 selects these):
+   the first start's passes are abandoned for the next start after OBCA_PATIENCE iterations.  Measured (tools/restart_study.py,
+   DESIGN.md): solves either converge well below it -- N = 5: <= 301 iterations, N = 20: <= 389, N = 74: ~500 per pass -- or
+   crawl at an indefinite point with delta_w ~ 1e3 until max_iter (3000 for obca_mpc4: 0.27 s on one wavefront), nothing in
+   between.  Later starts: the ones that succeed take 16-117 iterations from the window at N <= 20 (C3 gated, C5). */
 #define OBCA_PATIENCE(N) (500 + 10 * (N))
-#ifndef OBCA_RESTART_MAX_ITER        /* iteration limit of the restart pass: the restarts that succeed take 16-117 iterations at N <= 20 (C3 gated,
-                                        C5; tools/restart_study.py), one that does not would otherwise run to max_iter = 3000 */
-#define OBCA_RESTART_MAX_ITER(N) (300 + 10 * (N))
-#endif
+#define OBCA_RETRY_ITER(N) (300 + 10 * (N))
+/* One solve = at most three starts x two penalties (obca_mpc4 that converged with elastic variables left at the base penalty:
+   once more from the same start with rho x OBCA_RHO_ESCALATION; the next start begins at the base penalty again). */
+#define OBCA_MAX_PASSES 6
 #define OBCA_WINDOW_SPEED_FRAC 0.9
 
-/* Line-search filter capacity: a function of the problem SHAPE only, so that every kernel that can run a shape (and the
-   oracles) stops at the same point when the filter fills up (status OBCA_STATUS_NUMERIC): 64 entries for shapes the
-   one-wavefront kernel takes (<= 384 rows: one entry per lane), 128 for larger ones.  IPOPT's filter is unbounded; a
-   solve that fills 64 entries is stalling at the barrier floor. */
+/* Line-search filter capacity: a function of the problem SHAPE only, so that every kernel that can run a shape stops at the
+   same point when the filter fills up (status OBCA_STATUS_NUMERIC, answered by the next start of the ladder): 64 entries for
+   shapes the one-wavefront kernel takes (<= 384 rows: one entry per lane), 128 for larger ones.  IPOPT's filter is unbounded
+   and so is the oracles' (oracle/ipm_dense.py, oracle/obca_oracle.c): on a filter-full instance the kernels move to the next
+   start where the oracle keeps iterating -- a product deviation, met by ~1 of 8192 C2 instances. */
 #define OBCA_FILTER_CAP(R_max) ((R_max) <= 384 ? 64 : 128)
 
 #define OBCA_INST_DOUBLES 64   /* LDS reserved for the per-instance constant block (struct Inst) */
@@ -77,12 +89,18 @@
 #endif
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
-/* restart: a second start exists (0 / 1); start: where the FIRST pass begins -- 0 the reference's all-zero cold start (the
-   second start is the reference window then), 1 the reference window (the second start is the cold start).  obca_params.restart
-   carries both (include/obca_mpc.h): OBCA_OPT_RESTART / OBCA_OPT_START decode it the same way everywhere. */
-struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, restart, start, pad_; };
-#define OBCA_OPT_RESTART(r) (((r) < 0 || (r) == 2) ? 0 : 1)
-#define OBCA_OPT_START(r) ((r) >= 1 ? 1 : 0)
+/* order: obca_params.start_order (validated); nstarts: 1 (single_start) or 3; patience / retry_iter: resolved (> 0) */
+struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, order, nstarts, patience, retry_iter, pad_; };
+/* the four start fields of obca_params -> their resolved form; false: start_order / single_start outside its range */
+static inline bool obca_resolve_starts(ObcaOptsDev* o, int start_order, int single_start, int patience, int retry_iter, int N) {
+    if (start_order < OBCA_START_X0_FIRST || start_order > OBCA_START_ZEROS_FIRST || single_start < 0 || single_start > 1) return false;
+    o->order = start_order;
+    o->nstarts = single_start ? 1 : 3;
+    o->patience = patience > 0 ? patience : OBCA_PATIENCE(N);
+    o->retry_iter = retry_iter > 0 ? retry_iter : OBCA_RETRY_ITER(N);
+    o->pad_ = 0;
+    return true;
+}
 struct ObcaParamsDev {
     ObcaWeightsDev free_time, fixed_time;
     double xL[2], xU[2], uL[2], uU[2];

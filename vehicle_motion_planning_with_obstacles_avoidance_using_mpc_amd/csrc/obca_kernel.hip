@@ -1523,7 +1523,7 @@ __device__ __forceinline__ int riccati(const Lay& L, const Sh& S, const Inst& in
     return 0;
 }
 
-// Start point of the restart phase (oracle/ipm_dense.py:window_start): poses of the reference window (first pose x0), inputs
+// The window start of the ladder (oracle/ipm_dense.py:window_start): poses of the reference window (first pose x0), inputs
 // by differences clipped to their box, free-time problem (iT >= 0): the time scale at which the window is driven at
 // OBCA_WINDOW_SPEED_FRAC of the speed bound; lambda = mu = 0 (x is zero on entry).  Rare, one lane, out of line with scalar
 // arguments only: inlined into the body it cost the four-wavefront kernels 400 B of scratch.
@@ -1583,7 +1583,7 @@ struct ObcaHead {
 typedef const __attribute__((address_space(4))) ObcaLaunch ObcaLaunchConst;   // descriptor in HBM, read through the scalar cache
 
 template <int RPL, bool FROM_MEMORY = false, class DESC = const ObcaLaunch>
-__device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const int pass) {
+__device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const bool first) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     ObcaHead A;
@@ -1606,30 +1606,37 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     {   // anything but obca_mpc4 / 6 / 8, or obca_mpc6 without its terminal set: a per-instance error, nothing is solved
         const int v = A.variant[inst];
         if ((v != 4 && v != 6 && v != 8) || (v == 6 && A.term == nullptr)) {
-            if (lane == 0 && !pass) { A.status[inst] = OBCA_STATUS_BAD_VARIANT; A.iters[inst] = 0; }
+            if (lane == 0 && first) { A.status[inst] = OBCA_STATUS_BAD_VARIANT; A.iters[inst] = 0; }
             return;
         }
     }
-    // The caller runs the body up to three times per instance (same rule in oracle/ipm_dense.py:solve):
-    //   pass 0  the reference's cold start (or the caller's optional warm start);
-    //   pass 1  penalty escalation, free-time problem only: the l1 penalty is exact only while rho exceeds the multipliers.
-    //           If obca_mpc4 converged with elastic variables left -- what "infeasible" looks like, but also what a too small
-    //           rho looks like (the open-loop problem of demo1 at N = 10) -- once more from the cold start with rho x 100;
-    //   pass 2  restart phase, every variant: a solve that still has no feasible point (infeasible stationary point of the
-    //           penalty problem, line-search failure, iteration limit, filter full) is repeated from the reference window
-    //           with barrier parameter OBCA_RESTART_MU.
-    // Every other instance returns here.  A genuinely infeasible problem stays infeasible.
-    // obca_params.restart = 1 / 2 ("window first"): the starts change places -- passes 0 and 1 begin at the reference window,
-    // pass 2 at the reference's cold start.
-    double rho_mult = 1.0;
-    bool from_window = Ain.prm.opt.start != 0;
-    if (pass) {
+    // The caller runs the body up to OBCA_MAX_PASSES times per instance: the start ladder (same rule in oracle/ipm_dense.py:solve
+    // and csrc/obca_lpi_core.h:run_instance).  first: the first start of the order (include/obca_mpc.h: start_order; default
+    // x0 -> reference window -> zeros).  Every further call looks at how the previous one ended:
+    //   * feasible point (or nothing to solve): return;
+    //   * obca_mpc4 converged with elastic variables left at the base penalty: the l1 penalty is exact only while rho exceeds
+    //     the multipliers, so this is what "infeasible" looks like but also what a too small rho looks like (the open-loop
+    //     problem of demo1 at N = 10) -- the SAME start again with rho x 100;
+    //   * anything else without a feasible point (infeasible stationary point of the penalty problem, line-search failure,
+    //     iteration limit, filter full): the NEXT start of the order, if there is one, at the base penalty again (measured:
+    //     keeping the raised penalty makes starts fail that succeed at the base one).
+    // That is at most three starts x two penalties = OBCA_MAX_PASSES solves.  A genuinely infeasible problem stays
+    // infeasible.  The state of the ladder lives in LDS (it must survive from call to call, and nothing of it may occupy a
+    // register during the solve).
+    __shared__ int ladder_state[4];      // [0] current start already repeated with the raised penalty, [1] iterations, [2] factorisations so far, [3] index of the current start
+    const int order = Ain.prm.opt.order;
+    int start_s = 0, escalated = 0;
+    if (!first) {
         const int st0 = __builtin_amdgcn_readfirstlane(A.status[inst]);     // wave-uniform: the flags below stay scalar
-        const bool esc = A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE;
-        if (pass == 1) { if (!esc) return; }
-        else { if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 == OBCA_STATUS_BAD_BOUNDS || Ain.prm.opt.restart == 0) return; from_window = !from_window; }
-        if (esc) rho_mult = OBCA_RHO_ESCALATION;
+        if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 < OBCA_STATUS_NUMERIC) return;
+        escalated = __builtin_amdgcn_readfirstlane(ladder_state[0]);
+        start_s = __builtin_amdgcn_readfirstlane(ladder_state[3]);
+        if (A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE && !escalated) escalated = 1;
+        else { escalated = 0; if (++start_s >= Ain.prm.opt.nstarts) return; }
     }
+    const double rho_mult = escalated ? OBCA_RHO_ESCALATION : 1.0;
+    const int kind = OBCA_START_KIND(order, start_s);
+    const bool from_window = kind == OBCA_KIND_WINDOW;
 
     // ---- layout ------------------------------------------------------------------------------------
     Lay L;
@@ -1747,21 +1754,27 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         }
         SYNC();
         const double dis = (S.xref[0 * N1 + L.N] - in.x0[0]) + (S.xref[1 * N1 + L.N] - in.x0[1]);   // signed sum (q3)
-        if (lane == 0) in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
+        if (lane == 0) {
+            in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
+            // (every thread read the ladder's state before the barriers above)
+            ladder_state[0] = escalated; ladder_state[3] = start_s;
+            if (first) { ladder_state[1] = 0; ladder_state[2] = 0; }
+        }
     }
     SYNC();
 
     ObcaOptsDev O;
     O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho * rho_mult; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed; O.max_soc = Ain.prm.opt.max_soc;          // by value: A may live in HBM (fused closed-loop kernel)
     const int max_iter_v = L.free_T ? O.max_iter_free : O.max_iter_fixed;
-    const int max_iter_w = from_window ? OBCA_RESTART_MAX_ITER(L.N) : (Ain.prm.opt.restart ? OBCA_PATIENCE(L.N) : max_iter_v);
+    const int max_iter_w = Ain.prm.opt.nstarts == 1 ? max_iter_v : (start_s == 0 ? Ain.prm.opt.patience : Ain.prm.opt.retry_iter);   // include/obca_mpc.h: patience
     const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
 
-    // ---- start point: zeros, Topt = 1 (obca.py:856) -- or, when the caller asked for it (obca_set_warm_start; the
-    // reference never does), the previous solve's primal vector moved one stage forward (last stage repeated)
-    const bool warm = !from_window && A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
+    // ---- start point: zeros, Topt = 1 (obca.py:856), then by kind: every pose at x0 / the reference window / nothing -- or,
+    // when the caller asked for it (obca_set_warm_start; the reference never does) and this is the order's first cold
+    // start, the previous solve's primal vector moved one stage forward (last stage repeated)
+    const bool warm = kind == OBCA_WARM_KIND(order) && A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
     if (warm) {
         const double* zp = A.warm_z + (size_t)inst * A.n_max;
         const int blk = L.NS - 2;                              // pose, lambda, mu of a stage (inputs handled apart)
@@ -1784,6 +1797,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
     SYNC();
     if (!warm && L.free_T && lane == 0) S.x[L.iT()] = 1.0;
     if (from_window && lane == 0) window_start_point(S.x, S.xref, &in, L.N, L.NS, L.free_T ? L.iT() : -1);
+    // x0 start: where IPOPT's first full Newton step lands from the all-zero start (the dynamics linearised at v = 0 read
+    // x_{k+1} = x_k, the initial condition x_0 = x0)
+    if (kind == OBCA_KIND_X0 && !warm) for (int t = lane; t < 3 * (L.N + 1); t += NT) { const int k = t / 3; S.x[L.ip(k) + (t - 3 * k)] = in.x0[t - 3 * k]; }
     SYNC();
     int status = OBCA_STATUS_MAXITER;
     int it = 0, nfact = 0;
@@ -2366,36 +2382,63 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const i
         if (lane == 0) {
             A.ts_opt[inst] = L.free_T ? S.x[L.iT()] * in.Ts : in.Ts;
             A.status[inst] = status;
-            A.iters[inst] = it + (pass ? A.iters[inst] : 0);
+            // (counts of the whole sequence of passes; accumulated in LDS so that the pass number is dead after the prologue)
+            const int itot = it + ladder_state[1], ftot = nfact + ladder_state[2];
+            ladder_state[1] = itot; ladder_state[2] = ftot;
+            A.iters[inst] = itot;
             if (A.info) {
                 double* io = A.info + (size_t)inst * 4;
-                io[0] = GET(IV_F) / sf; io[1] = GET(IV_EMAX); io[2] = GET(IV_E0); io[3] = (double)nfact + (pass ? io[3] : 0.0);
+                io[0] = GET(IV_F) / sf; io[1] = GET(IV_EMAX); io[2] = GET(IV_E0); io[3] = (double)ftot;
             }
         }
     }
 }
 
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
-// The solve and, for the instances that need them, the recovery passes (penalty escalation, restart phase): three inlined
-// copies of the body -- the hot one (pass 0) and two cold ones (passes 1 and 2) that return at once where they do not
-// apply.  Every copy reads its OWN descriptor (A2, A3 = further kernel arguments with the same content): were they all
-// to read A, the compiler would merge their identical prologue expressions and keep those values alive across the whole
-// first solve, which showed up as scratch traffic in the hot copy.
+// The solve and, for the instances that need them, the further passes of the start ladder (penalty escalation, next starts).
+// OBCA_PASS_LOOP = 0: OBCA_MAX_PASSES inlined copies of the body -- the hot one and cold ones that return at once where
+// nothing is left to do.  Every copy reads its OWN descriptor (A2, A3 = further kernel arguments with the same content): were
+// they all to read A, the compiler would merge their identical prologue expressions and keep those values alive across the
+// whole first solve, which showed up as scratch traffic in the hot copy.  (With the hot copy straight and a loop over ONE cold
+// copy -- or the cold passes in an out-of-line function -- the hot copy of the one-wavefront kernels needs 48-240 B of
+// scratch; tools/kernel_resources.py.)
+// OBCA_PASS_LOOP = 1: ONE copy of the body in a loop over the passes (a quarter of the code; the one-wavefront kernel then
+// spills one double).
+#ifndef OBCA_PASS_LOOP
+#define OBCA_PASS_LOOP 0
+#endif
 template <int RPL, class DESC>
 __device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
     const int inst = blockIdx.x;
-    obca_ipm_body<RPL, false, DESC>(A, inst, 0);
+#if OBCA_PASS_LOOP
+    if (inst >= A.B) return;
+    (void)A2; (void)A3;
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < OBCA_MAX_PASSES; ++pass) {
+        obca_ipm_body<RPL, false, DESC>(A, inst, pass == 0);
+        __syncthreads();                                        // status written by thread 0 of this workgroup
+        const int st = A.status[inst];
+        if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing (more) to recover
+    }
+#else
+    static_assert(OBCA_MAX_PASSES == 6, "one inlined copy of the body per pass");
+    obca_ipm_body<RPL, false, DESC>(A, inst, true);
     if (inst >= A.B) return;
     __syncthreads();                                            // status written by thread 0 of this workgroup
     {
         const int st = A2.status[inst];
         if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing to recover
     }
-    // (straight-line, not a loop over the passes: around a loop the compiler hoists the descriptor loads of the cold copy and
-    // the kernel needs 64-256 B of scratch; measured with tools/kernel_resources.py)
-    obca_ipm_body<RPL, false, DESC>(A2, inst, 1);
+    obca_ipm_body<RPL, false, DESC>(A2, inst, false);
     __syncthreads();
-    obca_ipm_body<RPL, false, DESC>(A3, inst, 2);
+    obca_ipm_body<RPL, false, DESC>(A3, inst, false);
+    __syncthreads();
+    obca_ipm_body<RPL, false, DESC>(A2, inst, false);
+    __syncthreads();
+    obca_ipm_body<RPL, false, DESC>(A3, inst, false);
+    __syncthreads();
+    obca_ipm_body<RPL, false, DESC>(A2, inst, false);
+#endif
 }
 // KARG: the descriptors are read through the kernarg segment pointer (constant address space) instead of the by-value
 // parameters.  Which form leaves the allocator more room differs from kernel to kernel (tools/kernel_resources.py): by value
@@ -2527,14 +2570,14 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
         const int g = __builtin_amdgcn_readfirstlane(ro_msg[1]);     // wave-uniform: the descriptor is read with scalar loads
         __syncthreads();
         if (running) {
-            // attempts 0..2: the three passes of the solve (cold start, penalty escalation, restart phase -- the body returns
-            // at once where a pass does not apply); attempts 3..5: the same for obca_mpc8 where obca_mpc6 failed (src/closed_loop.py:393-398).
-            // One call site: the body is inlined once.
-            for (int attempt = 0; attempt < 6; ++attempt) {
+            // attempts 0 .. P-1 (P = OBCA_MAX_PASSES): the passes of the solve (the start ladder -- the body returns at once where
+            // nothing is left to do); attempts P .. 2P-1: the same for obca_mpc8 where obca_mpc6 failed
+            // (src/closed_loop.py:393-398).  One call site: the body is inlined once.
+            for (int attempt = 0; attempt < 2 * OBCA_MAX_PASSES; ++attempt) {
                 const ObcaLaunch* Lp = launches + g;
-                if (attempt >= 3) {
+                if (attempt >= OBCA_MAX_PASSES) {
                     if (g == 0) break;
-                    if (attempt == 3) {
+                    if (attempt == OBCA_MAX_PASSES) {
                         if (lane == 0) ro_msg[0] = ro_retry(&D, g, b);
                         __syncthreads();
                         const int v8 = ro_msg[0];
@@ -2543,8 +2586,13 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
                     }
                     Lp = launches + g + rollout::MAX_GROUPS;
                 }
-                obca_ipm_body<RPL, false, ObcaLaunchConst>(*(ObcaLaunchConst*)Lp, b, attempt >= 3 ? attempt - 3 : attempt);
+                obca_ipm_body<RPL, false, ObcaLaunchConst>(*(ObcaLaunchConst*)Lp, b, attempt == 0 || attempt == OBCA_MAX_PASSES);
                 __syncthreads();
+                {   // nothing (more) to recover: on to obca_mpc8's turn, or out
+                    const int st = __builtin_amdgcn_readfirstlane(((ObcaLaunchConst*)Lp)->status[b]);
+                    if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC)
+                        attempt = (attempt < OBCA_MAX_PASSES ? OBCA_MAX_PASSES : 2 * OBCA_MAX_PASSES) - 1;
+                }
             }
             if (lane == 0) ro_finish(&D, b);
             __syncthreads();

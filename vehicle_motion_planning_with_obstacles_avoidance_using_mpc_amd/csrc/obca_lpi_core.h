@@ -991,16 +991,16 @@ LPI_FN double row_barrier_lpi(double lo, double up, bool eq, double s, double p,
 // ---------------------------------------------------------------- one instance, start to finish
 struct Out { int status, iters, nfact; double f, elastic, E0, ts_opt, sf; };
 
-// zwarm != nullptr: start from that primal vector moved one stage forward (last stage repeated) with barrier
-// parameter mu_warm (obca_set_warm_start); otherwise the reference's cold start, or -- restart phase, from_window --
-// the reference window as a trajectory (oracle/ipm_dense.py:window_start) with barrier parameter mu_warm
+// zwarm != nullptr: start from that primal vector moved one stage forward (last stage repeated; obca_set_warm_start); otherwise
+// start `kind` of the ladder (csrc/obca_device.h: OBCA_KIND_*; the window as a trajectory: oracle/ipm_dense.py:window_start).
+// mu0: the barrier parameter the pass begins with; iter_cap: its iteration limit beside max_iter_* (the caller's patience)
 LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaOptsDev& O,
-                          const double* zwarm = nullptr, double mu_warm = OBCA_MU_INIT, bool from_window = false) {
+                          const double* zwarm, double mu0, int kind, int iter_cap) {
     const int max_iter_v = L.free_T ? O.max_iter_free : O.max_iter_fixed;
-    const int max_iter_w = from_window ? OBCA_RESTART_MAX_ITER(L.N) : (O.restart ? OBCA_PATIENCE(L.N) : max_iter_v);
-    const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
+    const int max_iter = max_iter_v < iter_cap ? max_iter_v : iter_cap;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
+    const bool from_window = kind == OBCA_KIND_WINDOW;
     if (zwarm) {
         const int blk = L.NS - 2;
         for (int k = 0; k <= L.N; ++k) {
@@ -1017,11 +1017,9 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
     } else {
         for (int t = 0; t < L.n; ++t) S.x[t] = 0.0;
         if (L.free_T) S.x[L.iT()] = 1.0;
-#ifdef OBCA_COLD_AT_X0              /* experiment (tools/start_study.py): the cold start with every pose at x0 -- where
-                                       IPOPT's first full Newton step lands from the all-zero start (the dynamics linearised at v = 0
-                                       read x_{k+1} = x_k, the initial condition x_0 = x0) */
-        if (!from_window) for (int k = 0; k <= L.N; ++k) for (int j = 0; j < 3; ++j) S.x[L.ip(k) + j] = in.x0[j];
-#endif
+        // x0 start: every pose at x0 -- where IPOPT's first full Newton step lands from the all-zero start (the dynamics
+        // linearised at v = 0 read x_{k+1} = x_k, the initial condition x_0 = x0)
+        if (kind == OBCA_KIND_X0) for (int k = 0; k <= L.N; ++k) for (int j = 0; j < 3; ++j) S.x[L.ip(k) + j] = in.x0[j];
         if (from_window) {              // poses of the reference window, inputs by differences
             const int N1 = L.N + 1;
             for (int k = 0; k <= L.N; ++k)
@@ -1057,7 +1055,7 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
         rho = O.rho * sf;
     }
     f = eval_objective<true>(L, S, in, S.x, sf, 0);
-    double mu = (zwarm || from_window) ? mu_warm : OBCA_MU_INIT;
+    double mu = mu0;
     bool bad_bounds = false;
     for (int r = 0; r < L.R; ++r) {
         double lo, up;
@@ -1452,32 +1450,33 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     const double dis = (S.xref[0 * N1 + L.N] - in.x0[0]) + (S.xref[1 * N1 + L.N] - in.x0[1]);
     in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
     const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
-    // obca_params.restart = 1 / 2 ("window first"): the two starts change places (csrc/obca_kernel.hip: obca_ipm_body) -- the first
-    // two passes begin at the reference window, the last one at the cold start (or the caller's optional warm start)
-    const bool win1 = A.prm.opt.start != 0;
-    const double* zw = warm ? A.warm_z + inst * (size_t)A.n_max : nullptr;
-    const double* z_first = win1 ? nullptr : zw;
-    const double* z_second = win1 ? zw : nullptr;
-    const double mu_first = win1 ? OBCA_RESTART_MU : A.warm_mu, mu_second = win1 ? A.warm_mu : OBCA_RESTART_MU;
-    Out o = solve_instance(L, S, in, A.prm.opt, z_first, mu_first, win1);
-    if (o.status == OBCA_STATUS_INFEASIBLE && L.free_T) {
-        // one penalty escalation for the free-time problem (the l1 penalty is exact only while rho exceeds the
-        // multipliers): the same solve again with rho x 100 -- see csrc/obca_kernel.hip
-        ObcaOptsDev O2 = A.prm.opt;
-        O2.rho *= OBCA_RHO_ESCALATION;
-        const Out o1 = o;
-        o = solve_instance(L, S, in, O2, z_first, mu_first, win1);
-        o.iters += o1.iters; o.nfact += o1.nfact;
+    // The start ladder (oracle/ipm_dense.py:solve; csrc/obca_kernel.hip runs the same passes): the starts of the order one after
+    // the other until one ends at a feasible point; a free-time solve that converged with elastic variables left is first
+    // repeated from the same start with rho x OBCA_RHO_ESCALATION (the next start begins at the base penalty again).  The caller's
+    // optional warm start takes the place of the first cold start of the order.
+    const ObcaOptsDev& O0 = A.prm.opt;
+    const int max_iter_v = L.free_T ? O0.max_iter_free : O0.max_iter_fixed;
+    Out o;
+    o.status = OBCA_STATUS_MAXITER;
+    int iters = 0, nfact = 0;
+    for (int s = 0; s < O0.nstarts; ++s) {
+        if (s > 0 && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) break;
+        const int kind = OBCA_START_KIND(O0.order, s);
+        const int cap = O0.nstarts == 1 ? max_iter_v : (s == 0 ? O0.patience : O0.retry_iter);
+        const bool use_warm = warm && kind == OBCA_WARM_KIND(O0.order);
+        const double* z = use_warm ? A.warm_z + inst * (size_t)A.n_max : nullptr;
+        const double mu0 = use_warm ? A.warm_mu : (kind == OBCA_KIND_WINDOW ? OBCA_RESTART_MU : OBCA_MU_INIT);
+        o = solve_instance(L, S, in, O0, z, mu0, kind, cap);
+        iters += o.iters; nfact += o.nfact;
+        if (o.status == OBCA_STATUS_INFEASIBLE && L.free_T) {
+            // the l1 penalty is exact only while rho exceeds the multipliers: "rho too small" looks like "infeasible"
+            ObcaOptsDev O = O0;
+            O.rho *= OBCA_RHO_ESCALATION;
+            o = solve_instance(L, S, in, O, z, mu0, kind, cap);
+            iters += o.iters; nfact += o.nfact;
+        }
     }
-    if (A.prm.opt.restart && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
-        // restart phase (every variant; oracle/ipm_dense.py:solve): the solve has not reached a feasible point from its first
-        // start -- once more from the other one (default order: the reference window, barrier parameter OBCA_RESTART_MU)
-        ObcaOptsDev O3 = A.prm.opt;
-        if (L.free_T && o.status == OBCA_STATUS_INFEASIBLE) O3.rho *= OBCA_RHO_ESCALATION;
-        const Out o1 = o;
-        o = solve_instance(L, S, in, O3, z_second, mu_second, !win1);
-        o.iters += o1.iters; o.nfact += o1.nfact;
-    }
+    o.iters = iters; o.nfact = nfact;
     if (A.warm_z != nullptr && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE)) {
         double* zp = A.warm_z + inst * (size_t)A.n_max;
         for (int t = 0; t < L.n; ++t) zp[t] = S.x[t];

@@ -206,11 +206,11 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
         for (int a = 0; a < 2; ++a) {
             int64_t lds = 0;
             int wave_ok = 0;
-            // obca_mpc6 (a = 0 of the groups with sensed boxes) runs without the restart phase: its failure is answered by
-            // obca_mpc8 on the same inputs (src/closed_loop.py:393-398); obca_mpc4 and obca_mpc8, after which the reference
-            // stops the rollout (:401-413), keep it
+            // obca_mpc6 (a = 0 of the groups with sensed boxes) runs the first start of the order only: its failure is answered
+            // by obca_mpc8 on the same inputs (src/closed_loop.py:393-398); obca_mpc4 and obca_mpc8, after which the reference
+            // stops the rollout (:401-413), run the whole ladder
             obca_params pg = r->params;
-            if (g > 0 && a == 0) pg.restart = pg.restart >= 1 ? 2 : -1;    // (one start only: the window if that is the first)
+            if (g > 0 && a == 0) pg.single_start = 1;
             const int rc = obca_internal_fill_launch(r->solver[g], a ? D.var8[g] : D.var[g], D.B, D.x0, D.u0, g == 0 ? D.xref : D.xref_fix, D.A[g], D.b[g],
                                                      D.Ts, D.term, &pg, D.xopt[g], D.uopt[g], D.ts[g],
                                                      a ? D.status8[g] : D.status[g], a ? D.iters8[g] : D.iters[g], nullptr,
@@ -251,7 +251,7 @@ extern "C" int obca_rollouts_step(obca_rollouts* r, void* hip_stream) {
         hipStream_t gs = g == 0 ? s : r->gstream[g];
         if (g > 0 && hipStreamWaitEvent(gs, r->fork, 0) != hipSuccess) return OBCA_E_HIP;
         obca_params pg = r->params;
-        if (g > 0) pg.restart = pg.restart >= 1 ? 2 : -1;   // obca_mpc6: obca_mpc8 follows (see obca_rollouts_reset)
+        if (g > 0) pg.single_start = 1;   // obca_mpc6: obca_mpc8 follows (see obca_rollouts_reset)
         int rc = obca_solve_batch(r->solver[g], D.var[g], D.B, D.x0, D.u0, g == 0 ? D.xref : D.xref_fix, D.A[g], D.b[g], D.Ts, D.term, &pg,
                                   D.xopt[g], D.uopt[g], D.ts[g], D.status[g], D.iters[g], nullptr, (void*)gs);
         if (rc != OBCA_OK) return rc;

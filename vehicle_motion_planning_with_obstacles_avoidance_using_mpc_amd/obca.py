@@ -17,12 +17,12 @@ from .solver import BatchSolver, SolverParams, pack_reference_call
 class obca:
     def __init__(self):
         self._solvers = {}
-        # the restart phase of obca_mpc6 (include/obca_mpc.h: restart).  On for a bare call; a driver that answers a failed
-        # obca_mpc6 with obca_mpc8 itself (this package's closedLoop) switches it off
-        self.restart_obca_mpc6 = True
-        # "window first" (include/obca_mpc.h: restart = 1 / 2): the reference window as the first start of every solve, the
-        # reference's all-zero cold start as the second.  Off by default: the reference cold-starts (src/obca.py:856).
-        self.window_first = False
+        # The start ladder of every solve (include/obca_mpc.h: start_order): "x0" (default) x0 -> reference window -> zeros,
+        # "window" the reference window first, "zeros" the reference's literal all-zero start first (src/obca.py:856).
+        self.start_order = "x0"
+        # True: every call runs the first start of the order only.  A driver that answers a failed obca_mpc6 with obca_mpc8
+        # itself (this package's closedLoop) asks for that per call instead: obca_mpc6(..., single_start=True).
+        self.single_start = False
 
     def _solver(self, N, m):
         key = (int(N), tuple(m))
@@ -36,15 +36,11 @@ class obca:
         return self._solvers[key]
 
     def _run(self, variant, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0,
-             terminal_set=None):
+             terminal_set=None, single_start=False):
         m, x0v, u0v, xr, A, b, Tsv, term = pack_reference_call(variant, Ts, N, x0, xref, nObs, vObs, AObs, bObs, u0,
                                                                 terminal_set)
         kw = dict(xL=xL, xU=xU, uL=uL, uU=uU, ego=ego, dmin=dmin)
-        one_start = (variant == 6 and not self.restart_obca_mpc6) or not getattr(self, "restart_all", True)
-        if self.window_first:
-            kw["restart"] = 2 if one_start else 1
-        elif one_start:
-            kw["restart"] = -1
+        kw.update(start_order=self.start_order, single_start=bool(single_start or self.single_start))
         if variant == 4:
             prm = SolverParams(Q_free=Q, R_free=R, P_free=P, **kw)
         else:
@@ -62,9 +58,11 @@ class obca:
         return self._run(4, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0)
 
     def obca_mpc6(self, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, uOpt,
-                  terminal_set):
+                  terminal_set, single_start=False):
+        """single_start (not a reference argument): the first start of the ladder only -- for a caller whose own fallback
+        (obca_mpc8, src/closed_loop.py:393-398) follows a failure"""
         return self._run(6, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0,
-                         terminal_set)
+                         terminal_set, single_start=single_start)
 
     def obca_mpc8(self, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, uOpt):
         return self._run(8, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0)

@@ -34,7 +34,8 @@ class SolverParams:
     def __init__(self, xL=(0.0, 0.0), xU=(39.0, 10.0), uL=(-0.6, -math.pi / 6), uU=(0.6, math.pi / 6),
                  ego=DEFAULT_EGO, dmin=0.05,
                  Q_free=None, R_free=None, P_free=None, Q_fix=None, R_fix=None, P_fix=None,
-                 tol=0.0, rho=0.0, feas_tol=0.0, max_iter_free=0, max_iter_fixed=0, max_soc=0, restart=0):
+                 tol=0.0, rho=0.0, feas_tol=0.0, max_iter_free=0, max_iter_fixed=0, max_soc=0,
+                 start_order=0, single_start=False, patience=0, retry_iter=0):
         self.xL, self.xU, self.uL, self.uU = [tuple(float(v) for v in a[:2]) for a in (xL, xU, uL, uU)]
         self.ego = tuple(float(v) for v in ego)
         self.dmin = float(dmin)
@@ -48,7 +49,11 @@ class SolverParams:
         self.tol, self.rho, self.feas_tol = float(tol), float(rho), float(feas_tol)
         self.max_iter_free, self.max_iter_fixed = int(max_iter_free), int(max_iter_fixed)
         self.max_soc = int(max_soc)            # 0 = IPOPT's default (4), negative = no second-order correction
-        self.restart = int(restart)            # 0 cold start then window (default), < 0 cold start only, 1 window first, 2 window only (include/obca_mpc.h)
+        # the start ladder (include/obca_mpc.h): order "x0" (default: x0 -> window -> zeros) | "window" | "zeros" or the
+        # OBCA_START_* value; single_start: the first start only; patience / retry_iter: 0 = the defaults 500 + 10 N / 300 + 10 N
+        self.start_order = int(_lib.START_ORDERS.get(start_order, start_order))
+        self.single_start = bool(single_start)
+        self.patience, self.retry_iter = int(patience), int(retry_iter)
 
     def to_c(self):
         p = _lib.ObcaParams()
@@ -64,7 +69,8 @@ class SolverParams:
         p.tol, p.rho, p.feas_tol = self.tol, self.rho, self.feas_tol
         p.max_iter_free, p.max_iter_fixed = self.max_iter_free, self.max_iter_fixed
         p.max_soc = self.max_soc
-        p.restart = self.restart
+        p.start_order, p.single_start = self.start_order, int(self.single_start)
+        p.patience, p.retry_iter = self.patience, self.retry_iter
         return p
 
 
