@@ -29,7 +29,7 @@ ALG_BYTES = {(5, 6): 1320, (5, 12): 2184, (6, 6): 1528}       # SURVEY.md 8(d): 
 HBM_PEAK_GBPS = 8000.0                                          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
 VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9        # lanes the VALUs of the chip issue per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12
 
 
@@ -147,10 +147,10 @@ def cpu_baseline(batch, N):
             "sample": "%d instances of the same batch, structured core (csrc/obca_lpi_core.h) on the host, %d OpenMP threads, %.1f s" % (n, cores, dt)}
 
 
-_C3_BATCHES = {}          # generated once per run (the window_first leg solves the same instances)
+_C3_BATCHES = {}          # generated once per run (the start-order legs solve the same instances)
 
 
-def config_c3(B, N=20, restart=0):
+def config_c3(B, N=20, start_order=0):
     """Config C3: N=20, walls + box + two moving boxes, lidar-gated: the free-time sub-batch (obca_mpc4, three
     static obstacles) and the gated sub-batch (obca_mpc6, five obstacles, time-varying rows), B UNIQUE seeded instances
     each; both run on the four-wavefront LDS kernel."""
@@ -170,7 +170,7 @@ def config_c3(B, N=20, restart=0):
         for _ in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = s.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], SolverParams(restart=restart), out=out)
+            out = s.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], SolverParams(start_order=start_order), out=out)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
@@ -183,7 +183,7 @@ def config_c3(B, N=20, restart=0):
     return res
 
 
-def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66)), window_first=False):
+def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="x0"):
     """Row N3: the reference's open-loop free-time plan (closedLoop.mpc_openLoop_freeTime, src/closed_loop.py:113-120) as ONE
     instance through the drop-in `obca` class -- the only timing the reference publishes (src/simulation.py:230-231: N = 74
     136.69 s, N = 10 3.69 s, hardware unspecified).  Second call timed (the first allocates the handle's workspace)."""
@@ -191,11 +191,11 @@ def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66)), window_first=
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
     pub = {10: 3.69, 74: 136.69}
-    res = {"workload": "open-loop free-time plan (obca_mpc4, cold start, start/goal-only reference), batch of ONE, host call to host result",
+    res = {"workload": "open-loop free-time plan (obca_mpc4, default start ladder, start/goal-only reference), batch of ONE, host call to host result",
            "reference_published_s": {"N=10": 3.69, "N=74": 136.69, "source": "src/simulation.py:230-231, hardware unspecified"}}
     for demo, N in cases:
         s = obca()
-        s.window_first = window_first
+        s.start_order = start_order
         cl = closedLoop(problemSetting(demo), solver=s)
         cl.N_free = N
         cl.mpc_openLoop_freeTime()
@@ -217,9 +217,9 @@ def reference_gif_leg():
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
     ref = np.asarray(reference_gif.fixture()["spend_time"][1:])
     out = {"fixture": "tests/golden/reference_gif_demo9.json (83 steps, titles rounded to 0.01 s)", "tolerance_s": reference_gif.TIME_TOL}
-    for name, win in (("cold_start", False), ("window_first", True)):
+    for name in ("x0", "window", "zeros"):          # include/obca_mpc.h: start_order; "x0" is the default
         s = obca()
-        s.window_first = win
+        s.start_order = name
         iters = []
         run = s._run
         def counted(*a, **k):
@@ -231,16 +231,17 @@ def reference_gif_leg():
         cum, _, cl = reference_gif.replay(s, 83)
         n = min(len(cum), 83)
         bad = np.where(np.abs(cum[:n] - ref[:n]) > reference_gif.TIME_TOL)[0]
-        out[name] = {"steps_run": int(len(cum)), "consecutive_steps_matching_the_reference": int(bad[0]) if len(bad) else n,
+        out["start_order_" + name] = {"steps_run": int(len(cum)), "consecutive_steps_matching_the_reference": int(bad[0]) if len(bad) else n,
                      "steps_matching_in_total": int(n - len(bad)), "mean_ipm_iters": float(np.mean(iters)), "seconds": time.perf_counter() - t0}
     return out
 
 
-def window_first_leg(solver, dv, out0, B, steps=3):
-    """obca_params.restart = 1 on the headline batch: the reference window as the first start (NOT the default -- the reference
-    cold-starts); throughput, and how many instances end at the optimum the default order finds."""
+def start_order_leg(solver, dv, out0, B, order, steps=3):
+    """another obca_params.start_order on the headline batch ("window": the reference window as the first start; "zeros": the
+    reference's literal all-zero start first, the default until obca_mpc 0.1): throughput, and how many instances end at the
+    optimum the default order finds."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
-    prm1 = SolverParams(restart=1)
+    prm1 = SolverParams(start_order=order)
     x0, ts0, st0 = out0.xopt.clone(), out0.ts_opt.clone(), out0.status.clone()
     go = lambda: solver.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], prm1)
     o = go()
@@ -259,7 +260,7 @@ def window_first_leg(solver, dv, out0, B, steps=3):
             "same_optimum_as_the_default_order": int(same.sum().item()), "of_instances_both_solved": int(both.sum().item())}
 
 
-def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False, classify_max=None, restart=0):
+def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False, classify_max=None, start_order=0):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop per GPU, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds first .. first+B-1, resident in HBM
     before the clock starts.  With a process group every rank runs the whole loop for its own worlds (no collective on
@@ -268,9 +269,9 @@ def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=Fal
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
     w = pack_worlds([sc.make_world_c5(first + i, n_dyn=n_dyn) for i in range(B)])
     prm = None
-    if restart:
+    if start_order:
         from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
-        prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), restart=restart)
+        prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), start_order=start_order)
     dr = DeviceRollouts(w, N=5, warm_start=warm_start, params=prm)
     dr.run(1)
     torch.cuda.synchronize()
@@ -320,7 +321,7 @@ def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=Fal
                                     max(1, min(192, os.cpu_count() or 1)))
                 same = [r for r in rows if not r["replay_differs"]]
                 res["stopped_infeasible_split"] = {
-                    "sample": "%d of the %d stopped rollouts (lowest world indices%s)" % (len(stopped), n_stopped, "" if len(stopped) == n_stopped else "; --classify-all for every one: profiles/r03_bench_default_run.json"),
+                    "sample": "%d of the %d stopped rollouts (lowest world indices%s)" % (len(stopped), n_stopped, "" if len(stopped) == n_stopped else "; --classify-all for every one: profiles/r04_bench_default_run.json"),
                     "classified": len(same), "feasible_point_exists_solver_failure": int(sum(r["feasible_point_found"] for r in same)),
                     "no_feasible_point_found": int(sum(not r["feasible_point_found"] for r in same)),
                     "host_replay_stops_elsewhere": len(rows) - len(same),
@@ -458,7 +459,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2 generator (SURVEY 8d): demo1 corridor, 2 wall rows + 1 random box (M=%d), "
-                                   "random start along an A*-like lattice path, obca_mpc4 cold start, seed %d"
+                                   "random start along an A*-like lattice path, obca_mpc4, default start ladder (x0 -> window -> zeros), seed %d"
                                    % (M, sc.SEED0),
                        "batch_per_gpu": B, "horizon_N": N, "obstacles": 3, "variant": "obca_mpc4",
                        "parallelism": "shard%d" % world},
@@ -510,16 +511,22 @@ def main():
         if dist is None and args.closed_loop_rollouts > 0:
             # secondary figures: a failure in one of them must not cost the headline line
             def window_first_all():
-                r = window_first_leg(solver, dv, out, B)
-                r["note"] = "obca_params.restart = 1: the reference window as the first start of every solve (NOT the default: the reference cold-starts, src/obca.py:856)"
-                r["config_c3"] = config_c3(B, restart=1)
-                ol = open_loop(window_first=True)
+                r = start_order_leg(solver, dv, out, B, "window")
+                r["note"] = "obca_params.start_order = OBCA_START_WINDOW_FIRST: the reference window as the first start of every solve (NOT the default)"
+                r["config_c3"] = config_c3(B, start_order="window")
+                ol = open_loop(start_order="window")
                 r["open_loop"] = {k: v for k, v in ol.items() if isinstance(v, dict) and "seconds" in v}
-                c5 = closed_loop_c5(args.closed_loop_rollouts, restart=1)
+                c5 = closed_loop_c5(args.closed_loop_rollouts, start_order="window")
                 r["closed_loop"] = {k: c5[k] for k in ("value", "unit", "seconds", "converged_steps", "attempted_steps", "rollouts_to_step_cap", "rollouts_stopped_infeasible", "mean_ipm_iters") if k in c5}
+                return r
+
+            def zeros_first():
+                r = start_order_leg(solver, dv, out, B, "zeros")
+                r["note"] = "obca_params.start_order = OBCA_START_ZEROS_FIRST: the reference's literal all-zero start first (src/obca.py:856) -- the default of rounds 1-3, kept for comparison"
                 return r
             extras = (("reference_gif", reference_gif_leg),
                       ("window_first", window_first_all),
+                      ("zeros_first", zeros_first),
                       ("open_loop", open_loop),
                       ("config_c3", lambda: config_c3(B)),
                       ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts, classify=not args.no_cpu_baseline,

@@ -17,8 +17,8 @@ def main():
     ap.add_argument("demo", nargs="?", default="demo8")
     ap.add_argument("--monte-carlo", type=int, default=0, help="number of seeded C5 worlds instead of one demo")
     ap.add_argument("--warm-start", action="store_true", help="optional extension, not reference behaviour")
-    ap.add_argument("--window-first", action="store_true",
-                    help="obca_params.restart = 1: every solve starts from the reference window, the cold start second (DESIGN.md section 2)")
+    ap.add_argument("--start-order", choices=("x0", "window", "zeros"), default="x0",
+                    help="obca_params.start_order (include/obca_mpc.h): x0 -> window -> zeros (default), the reference window first, or the reference's literal all-zero start first")
     args = ap.parse_args()
     import __graft_entry__ as ge
     ge.build()
@@ -28,7 +28,7 @@ def main():
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
     if not args.monte_carlo:
         cl = closedLoop(problemSetting(args.demo))          # same attributes / methods as the reference class
-        cl.obca_solver.window_first = args.window_first
+        cl.obca_solver.start_order = args.start_order
         t0 = time.time()
         x_open, x_closed, u_closed, T_closed = cl.closed_loop_mpc4()
         print("%s: %d closed-loop steps in %.2f s, final pose %s, step lengths %s" % (
@@ -38,9 +38,9 @@ def main():
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
     w = pack_worlds([make_world_c5(i) for i in range(args.monte_carlo)])
     prm = None
-    if args.window_first:
+    if args.start_order != "x0":
         from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
-        prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), restart=1)
+        prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), start_order=args.start_order)
     dr = DeviceRollouts(w, N=5, warm_start=0.1 if args.warm_start else None, params=prm)
     torch.cuda.synchronize()
     t0 = time.time()

@@ -9,7 +9,8 @@ cases = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]] or [("de
 for demo, N in cases:
     s = obca()
     import os
-    if os.environ.get('NO_RESTART'): s.restart_all = False
+    if os.environ.get('SINGLE_START'): s.single_start = True
+    s.start_order = os.environ.get('START_ORDER', 'x0')
     cl = closedLoop(problemSetting(demo), solver=s)
     cl.N_free = N
     cl.mpc_openLoop_freeTime()

@@ -1,4 +1,4 @@
-"""dev tool: per-phase shader-clock shares of the solver (library built by tools/build_prof.sh with -DOBCA_PROFILE):
+"""dev tool: per-phase shader-clock shares of the solver (library built by tools/build_variant.sh prof -DOBCA_PROFILE):
 python tools/gpu_prof.py B c2|c3|c3free N"""
 import sys, ctypes, numpy as np, torch
 sys.path.insert(0, '.')

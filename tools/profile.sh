@@ -2,9 +2,9 @@
 # rocprofv3 evidence of a round (run on the MI355X box through gpurun): kernel trace + stats of the default bench, then the
 # counter passes -- each --pmc pass in its OWN run, never combined with trace domains other than --kernel-trace.
 # Outputs under gpurun_out/prof_<tag>/; tools/pmc_summary.py <tag> condenses them into profiles/.
-#   gpurun -- 'bash tools/profile.sh r03'   then here:   python tools/pmc_summary.py r03
+#   gpurun -- 'bash tools/profile.sh r04'   then here:   python tools/pmc_summary.py r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

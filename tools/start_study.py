@@ -1,16 +1,10 @@
-"""dev tool (CPU only): where should a solve START?  Builds the host build of the structured core (tests/native) three ways
-and replays the reference's own demo9 run (tests/golden/reference_gif_demo9.json, tests/reference_gif.py) plus a sample of
-the headline batch:
-  zeros    the reference's all-zero start (src/obca.py:856) -- the default
-  window   obca_params.restart = 1: the reference window first
-  x0       -DOBCA_COLD_AT_X0: the all-zero start with every pose at x0, i.e. the iterate IPOPT's first full Newton step
-           reaches from zeros (linearised at v = 0 the dynamics read x_{k+1} = x_k)
-Prints, per start: consecutive GIF steps matched, steps run, mean iterations; on the C2 sample: converged share, mean
-iterations, instances ending at the optimum of the zeros start.       python tools/start_study.py [n_c2_instances]"""
+"""dev tool (CPU only): the three start orders of obca_params.start_order (include/obca_mpc.h) on the host build of the
+structured core (tests/native): the reference's own demo9 run (tests/golden/reference_gif_demo9.json, tests/reference_gif.py)
+plus samples of the bench workloads.  Prints, per order: consecutive GIF steps matched, steps run, mean iterations; on the C2
+sample: converged share, mean iterations, instances ending at the optimum of the default order; C3 (N = 20) and C5 samples.
+    python tools/start_study.py [n_c2_instances]"""
 import os
-import subprocess
 import sys
-import tempfile
 
 import numpy as np
 
@@ -19,17 +13,6 @@ sys.path.insert(0, ROOT)
 from oracle import c_oracle                                              # noqa: E402
 from tests import native_build, reference_gif                            # noqa: E402
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc   # noqa: E402
-
-
-def build(flag, out):
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-Wno-unknown-pragmas"] +
-                   ([flag] if flag else []) + [native_build.SRC, "-o", out], check=True)
-
-
-def load(path):
-    native_build._lib = None
-    native_build.OUT, native_build.DEPS = path, []
-    return native_build.load()
 
 
 def main():
@@ -41,37 +24,31 @@ def main():
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import pack_worlds
     c3 = {g: sc.make_batch_c3(24, 20, gated=g, procs=8) for g in (False, True)}
     worlds = [sc.make_world_c5(i) for i in range(96)]
-    with tempfile.TemporaryDirectory() as tmp:
-        libs = {"zeros": (None, False), "window": (None, True), "x0": ("-DOBCA_COLD_AT_X0", False)}
-        for name, (flag, win) in libs.items():
-            path = os.path.join(tmp, "lib_%s.so" % ("x0" if flag else "plain"))
-            if not os.path.exists(path):
-                build(flag, path)
-            load(path)
-            s = native_build.LpiObca()
-            s.window_first = win
-            cum, _, cl = reference_gif.replay(s, 110)
-            k = min(len(cum), 83)
-            bad = np.where(np.abs(cum[:k] - ref[:k]) > reference_gif.TIME_TOL)[0]
-            o = native_build.lpi_solve(*args, params=c_oracle.default_params(restart=1 if win else 0))
-            ok = np.isin(o["status"], (0, 1))
-            if base is None:
-                base = o
-            same = ok & np.isin(base["status"], (0, 1)) & (np.abs(o["ts_opt"] - base["ts_opt"]) <= 1e-6 * np.maximum(1.0, np.abs(base["ts_opt"]))) & \
-                (np.abs(o["xopt"] - base["xopt"]).reshape(n, -1).max(1) <= 1e-5)
-            print("%-7s GIF: %2d consecutive steps of 83 (run: %d steps, goal %s, mean %.1f iterations) | C2 sample of %d: converged %.4f, "
-                  "mean %.1f iterations, %d at the optimum of the zeros start" %
-                  (name, int(bad[0]) if len(bad) else k, cl.k, cl.goal_reached(), np.mean([c["iters"] for c in s.calls]), n, ok.mean(),
-                   o["iters"].mean(), int(same.sum())), flush=True)
-            prm = c_oracle.default_params(restart=1 if win else 0)
-            for g in (False, True):
-                bb = c3[g]
-                o3 = native_build.lpi_solve(bb["variant"], 20, bb["m"], bb["x0"], bb["u0"], bb["xref"], bb["A"], bb["b"], bb["Ts"], bb["term"], params=prm)
-                print("        C3 %s, 24 instances at N = 20: converged %d, mean %.0f iterations" %
-                      ("gated obca_mpc6" if g else "free-time obca_mpc4", int(np.isin(o3["status"], (0, 1)).sum()), o3["iters"].mean()), flush=True)
-            r = native_build.rollout_run(pack_worlds(worlds), 5, prm, 30)
-            print("        C5, 96 rollouts x <= 30 steps: %d steps converged, %d rollouts stopped infeasible, mean %.0f iterations" %
-                  (int(r["steps"].sum()), int((r["flags"] == 3).sum()), r["iters"][r["variant"] > 0].mean()), flush=True)
+    for order in ("x0", "window", "zeros"):
+        s = native_build.LpiObca()
+        s.start_order = order
+        cum, _, cl = reference_gif.replay(s, 110)
+        k = min(len(cum), 83)
+        bad = np.where(np.abs(cum[:k] - ref[:k]) > reference_gif.TIME_TOL)[0]
+        prm = c_oracle.default_params(start_order=order)
+        o = native_build.lpi_solve(*args, params=prm)
+        ok = np.isin(o["status"], (0, 1))
+        if base is None:
+            base = o
+        same = ok & np.isin(base["status"], (0, 1)) & (np.abs(o["ts_opt"] - base["ts_opt"]) <= 1e-6 * np.maximum(1.0, np.abs(base["ts_opt"]))) & \
+            (np.abs(o["xopt"] - base["xopt"]).reshape(n, -1).max(1) <= 1e-5)
+        print("%-7s GIF: %2d consecutive steps of 83 (run: %d steps, goal %s, mean %.1f iterations) | C2 sample of %d: converged %.4f, "
+              "mean %.1f iterations, %d at the optimum of the default order" %
+              (order, int(bad[0]) if len(bad) else k, cl.k, cl.goal_reached(), np.mean([c["iters"] for c in s.calls]), n, ok.mean(),
+               o["iters"].mean(), int(same.sum())), flush=True)
+        for g in (False, True):
+            bb = c3[g]
+            o3 = native_build.lpi_solve(bb["variant"], 20, bb["m"], bb["x0"], bb["u0"], bb["xref"], bb["A"], bb["b"], bb["Ts"], bb["term"], params=prm)
+            print("        C3 %s, 24 instances at N = 20: converged %d, mean %.0f iterations" %
+                  ("gated obca_mpc6" if g else "free-time obca_mpc4", int(np.isin(o3["status"], (0, 1)).sum()), o3["iters"].mean()), flush=True)
+        r = native_build.rollout_run(pack_worlds(worlds), 5, prm, 30)
+        print("        C5, 96 rollouts x <= 30 steps: %d steps converged, %d rollouts stopped infeasible, mean %.0f iterations" %
+              (int(r["steps"].sum()), int((r["flags"] == 3).sum()), r["iters"][r["variant"] > 0].mean()), flush=True)
 
 
 if __name__ == "__main__":

@@ -57,7 +57,7 @@
 #define OBCA_WARM_KIND(o) ((o) == 2 ? OBCA_KIND_ZEROS : OBCA_KIND_X0)
 #define OBCA_RESTART_MU 1.0
 /* Iteration limits of the passes while further starts remain (obca_params.patience / retry_iter; <= 0 selects these):
-   the first start's passes are abandoned for the next start after OBCA_PATIENCE iterations.  Measured (tools/restart_study.py,
+   the first start's passes are abandoned for the next start after OBCA_PATIENCE iterations.  Measured (round 3, git history of tools/restart_study.py;
    DESIGN.md): solves either converge well below it -- N = 5: <= 301 iterations, N = 20: <= 389, N = 74: ~500 per pass -- or
    crawl at an indefinite point with delta_w ~ 1e3 until max_iter (3000 for obca_mpc4: 0.27 s on one wavefront), nothing in
    between.  Later starts: the ones that succeed take 16-117 iterations from the window at N <= 20 (C3 gated, C5). */
