@@ -3,7 +3,7 @@
 # library (git-ignored); objects under /tmp.  OBCA_LIB=libobca_mpc_<name>.so selects it in tools/gpu_variant_bench.py,
 # gpu_cmp_builds.py, gpu_prof.py.
 #   tools/build_variant.sh prof -DOBCA_PROFILE        per-phase shader-clock counters (tools/gpu_prof.py)
-#   tools/build_variant.sh loop -DOBCA_PASS_LOOP=1     one copy of the solver body in a loop over the ladder's passes
+#   tools/build_variant.sh straight -DOBCA_LOOP_R4=false -DOBCA_LOOP_R56=false     form of the ladder's passes per kernel (csrc/obca_kernel.hip: solve_passes)
 set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd/csrc"

@@ -2396,68 +2396,77 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
 
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
 // The solve and, for the instances that need them, the further passes of the start ladder (penalty escalation, next starts).
-// OBCA_PASS_LOOP = 0: OBCA_MAX_PASSES inlined copies of the body -- the hot one and cold ones that return at once where
-// nothing is left to do.  Every copy reads its OWN descriptor (A2, A3 = further kernel arguments with the same content): were
-// they all to read A, the compiler would merge their identical prologue expressions and keep those values alive across the
-// whole first solve, which showed up as scratch traffic in the hot copy.  (With the hot copy straight and a loop over ONE cold
-// copy -- or the cold passes in an out-of-line function -- the hot copy of the one-wavefront kernels needs 48-240 B of
-// scratch; tools/kernel_resources.py.)
-// OBCA_PASS_LOOP = 1: ONE copy of the body in a loop over the passes (a quarter of the code; the one-wavefront kernel then
-// spills one double).
-#ifndef OBCA_PASS_LOOP
-#define OBCA_PASS_LOOP 0
-#endif
-template <int RPL, class DESC>
+// Two forms, chosen per kernel by measurement (tools/build_variant.sh, tools/gpu_variant_bench.py, tools/kernel_resources.py):
+//   LOOP   ONE copy of the body in a loop over the passes.  One-wavefront kernels: one double of the hot loop is spilled
+//          (16 B of scratch) and the launch is still 3 % SHORTER than with the straight form (C2: 29.8 against 30.7 ms, M = 12:
+//          33.3 against 34.3 ms) at a sixth of the code.
+//   !LOOP  OBCA_MAX_PASSES inlined copies of the body -- the hot one and cold ones that return at once where nothing is left to
+//          do.  Every copy reads its OWN descriptor (A2, A3 = further kernel arguments with the same content): were they all to
+//          read A, the compiler would merge their identical prologue expressions and keep those values alive across the whole
+//          first solve.  Four-wavefront kernels: 0 / 48 B of scratch instead of 96 / 208 B, C3 free-time 60.1 against 61.8 ms,
+//          gated 300 against 321 ms per 2048 solves.
+// (Measured and rejected: the hot copy straight + a loop over ONE cold copy, or the cold passes in an out-of-line function -- the
+// hot copy then needs 48-240 B of scratch, or the callee 1.9 KB for its callee-saved registers.)
+template <int RPL, bool LOOP, class DESC>
 __device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
     const int inst = blockIdx.x;
-#if OBCA_PASS_LOOP
-    if (inst >= A.B) return;
-    (void)A2; (void)A3;
+    if constexpr (LOOP) {
+        if (inst >= A.B) return;
 #pragma clang loop unroll(disable)
-    for (int pass = 0; pass < OBCA_MAX_PASSES; ++pass) {
-        obca_ipm_body<RPL, false, DESC>(A, inst, pass == 0);
-        __syncthreads();                                        // status written by thread 0 of this workgroup
-        const int st = A.status[inst];
-        if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing (more) to recover
+        for (int pass = 0; pass < OBCA_MAX_PASSES; ++pass) {
+            obca_ipm_body<RPL, false, DESC>(A, inst, pass == 0);
+            __syncthreads();                                        // status written by thread 0 of this workgroup
+            const int st = A.status[inst];
+            if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing (more) to recover
+        }
+    } else {
+        static_assert(OBCA_MAX_PASSES == 6, "one inlined copy of the body per pass");
+        obca_ipm_body<RPL, false, DESC>(A, inst, true);
+        if (inst >= A.B) return;
+        __syncthreads();                                            // status written by thread 0 of this workgroup
+        {
+            const int st = A2.status[inst];
+            if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing to recover
+        }
+        obca_ipm_body<RPL, false, DESC>(A2, inst, false);
+        __syncthreads();
+        obca_ipm_body<RPL, false, DESC>(A3, inst, false);
+        __syncthreads();
+        obca_ipm_body<RPL, false, DESC>(A2, inst, false);
+        __syncthreads();
+        obca_ipm_body<RPL, false, DESC>(A3, inst, false);
+        __syncthreads();
+        obca_ipm_body<RPL, false, DESC>(A2, inst, false);
     }
-#else
-    static_assert(OBCA_MAX_PASSES == 6, "one inlined copy of the body per pass");
-    obca_ipm_body<RPL, false, DESC>(A, inst, true);
-    if (inst >= A.B) return;
-    __syncthreads();                                            // status written by thread 0 of this workgroup
-    {
-        const int st = A2.status[inst];
-        if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing to recover
-    }
-    obca_ipm_body<RPL, false, DESC>(A2, inst, false);
-    __syncthreads();
-    obca_ipm_body<RPL, false, DESC>(A3, inst, false);
-    __syncthreads();
-    obca_ipm_body<RPL, false, DESC>(A2, inst, false);
-    __syncthreads();
-    obca_ipm_body<RPL, false, DESC>(A3, inst, false);
-    __syncthreads();
-    obca_ipm_body<RPL, false, DESC>(A2, inst, false);
-#endif
 }
 // KARG: the descriptors are read through the kernarg segment pointer (constant address space) instead of the by-value
-// parameters.  Which form leaves the allocator more room differs from kernel to kernel (tools/kernel_resources.py): by value
-// the one-wavefront kernels need no scratch (through the pointer 80 B), through the pointer obca_ipm_kernel_mw_r3 needs none
-// (by value 80 B).
-template <int RPL, bool KARG = false>
+// parameters.  Which form leaves the allocator more room differs from kernel to kernel (tools/kernel_resources.py).
+template <int RPL, bool LOOP, bool KARG = false>
 __device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const ObcaLaunch& A2, const ObcaLaunch& A3) {
     if constexpr (KARG) {
         ObcaLaunchConst* Ap = (ObcaLaunchConst*)__builtin_amdgcn_kernarg_segment_ptr();
-        solve_passes<RPL, ObcaLaunchConst>(Ap[0], Ap[1], Ap[2]);
+        solve_passes<RPL, LOOP, ObcaLaunchConst>(Ap[0], Ap[1], Ap[2]);
     } else {
-        solve_passes<RPL, const ObcaLaunch>(A, A2, A3);
+        solve_passes<RPL, LOOP, const ObcaLaunch>(A, A2, A3);
     }
 }
 
+#ifndef OBCA_LOOP_R4          /* form of solve_passes per kernel (see above); overridable for A/B builds (tools/build_variant.sh) */
+#define OBCA_LOOP_R4 true
+#endif
+#ifndef OBCA_LOOP_R56
+#define OBCA_LOOP_R56 true
+#endif
+#ifndef OBCA_LOOP_MW
+#define OBCA_LOOP_MW false
+#endif
+#ifndef OBCA_LOOP_GM
+#define OBCA_LOOP_GM true
+#endif
 #if OBCA_NT == 64
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<4>(A, A2, A3); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5>(A, A2, A3); }
-extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<6>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<4, OBCA_LOOP_R4>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5, OBCA_LOOP_R56>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<6, OBCA_LOOP_R56>(A, A2, A3); }
 
 // ================================================================== fused closed loop
 // One wavefront runs one step of one rollout at a time: lane 0 runs the harness of csrc/obca_rollout_core.h around
@@ -2646,10 +2655,10 @@ obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches,
 #define OBCA_KARG_R5 true
 #endif
 // four wavefronts per instance: rows r = thread + 256 j, j < 3 (up to 768 rows) or j < 5 (up to 1280 rows)
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<3, OBCA_KARG_R3>(A, A2, A3); }
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<-5, OBCA_KARG_R5>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<3, OBCA_LOOP_MW, OBCA_KARG_R3>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<-5, OBCA_LOOP_MW, OBCA_KARG_R5>(A, A2, A3); }
 // shapes beyond the LDS / beyond 1280 rows (long horizons: N = 74 with five obstacles has 3976 rows): four wavefronts per
 // instance, row state and every O(rows) array in the instance's slice of an HBM workspace (L2 resident), the O(N) blocks of
 // the stage-serial Riccati sweep in LDS
-extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_gm(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<0>(A, A2, A3); }
+extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_gm(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<0, OBCA_LOOP_GM>(A, A2, A3); }
 #endif
