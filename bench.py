@@ -370,7 +370,8 @@ def main():
             dist.barrier()
 
     B, N = args.batch, args.horizon
-    batch = sc.make_batch(B, N, three_boxes=args.three_boxes, first=rank * B)      # shard: instances rank*B ..
+    batch = sc.make_batch(B, N, three_boxes=args.three_boxes, first=rank * B,             # shard: instances rank*B ..
+                          procs=max(1, min(16, (os.cpu_count() or 1) // max(world, 1))))
     M = sum(batch["m"])
     solver = BatchSolver(N, batch["m"], max_batch=B, device=dev)
     solver_rows = 3 + 3 * N + 3 + 2 * (N + 1) + 4 * N + 2 + (N + 1) * (2 * len(batch["m"]) + M + 4 * len(batch["m"]))

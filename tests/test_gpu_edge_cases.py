@@ -1,6 +1,7 @@
 """Edge cases of the C ABI on the device: empty and masked batches, argument errors, the compiled size limits, the
 three-box (M=12) sub-configuration of C2, instance skipping."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -120,22 +121,33 @@ def test_compiled_size_limits():
 
 
 def test_c4_total_size_on_one_gpu():
-    """C4 is 65 536 instances over 8 GPUs; the whole of it also fits one (86 MB of inputs and outputs): replicas of
-    256 generator instances must give bit-identical answers wherever they sit in the grid"""
+    """C4 is 65 536 instances over 8 GPUs; the whole of it also fits one (86 MB of inputs and outputs).  65 536 UNIQUE seeds
+    (generator in parallel processes): every instance converges, its plan ends on the window's last pose, and the eight
+    contiguous shards an 8-GPU run would solve (sharding.shard_bounds) give, solved one after the other on this GPU, the
+    same words as the one big launch -- an instance's answer does not depend on where in which batch it sits."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.sharding import shard_bounds
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver
-    B, U = 65536, 256
-    small = sc.make_batch(U, 5)
-    b = {k: (np.concatenate([v] * (B // U)) if isinstance(v, np.ndarray) else v) for k, v in small.items()}
+    B, world = 65536, 8
+    b = sc.make_batch(B, 5, procs=max(1, min(64, os.cpu_count() or 1)))
+    assert len(np.unique(b["x0"], axis=0)) == B
     s = BatchSolver(5, b["m"], max_batch=B)
     d = _dev(b)
     out = s.solve(d["variant"], d["x0"], d["u0"], d["xref"], d["A"], d["b"], d["Ts"], d["term"])
     torch.cuda.synchronize()
-    x = out.xopt.view(B // U, U, 3, 6)
-    assert torch.equal(x[0], x[-1]) and torch.equal(x[0], x[B // U // 2])
-    st = out.status.view(B // U, U)
-    assert torch.equal(st[0], st[-1]) and ((st[0] == 0) | (st[0] == 1)).float().mean() > 0.95
+    ok = (out.status == 0) | (out.status == 1)
+    assert int(ok.sum()) >= B - 8, int(ok.sum())                      # measured: 65 536 of 65 536
+    end = (out.xopt[:, :, -1] - d["xref"][:, :, -1]).abs().amax(dim=1)
+    assert float(end[ok].max()) < 1e-6                               # terminal equality
+    xo, st, it = out.xopt.clone(), out.status.clone(), out.iters.clone()
     s.close()
+    s8 = BatchSolver(5, b["m"], max_batch=B // world)
+    for r in range(world):
+        lo, hi = shard_bounds(B, world, r)
+        o = s8.solve(*[d[k][lo:hi].contiguous() for k in ("variant", "x0", "u0", "xref", "A", "b", "Ts", "term")])
+        torch.cuda.synchronize()
+        assert torch.equal(o.xopt, xo[lo:hi]) and torch.equal(o.status, st[lo:hi]) and torch.equal(o.iters, it[lo:hi]), r
+    s8.close()
 
 
 def test_status_and_iterations_do_not_depend_on_the_kernel():

@@ -150,9 +150,44 @@ def make_instance(i, N=5, seed0=SEED0, three_boxes=False):
     raise RuntimeError("could not draw a feasible instance for seed %d" % (seed0 + i))
 
 
-def make_batch(B, N=5, seed0=SEED0, three_boxes=False, first=0):
-    """Arrays in the layout of include/obca_mpc.h for instances first .. first+B-1 (variant 4)."""
-    ins = [make_instance(first + i, N, seed0, three_boxes) for i in range(B)]
+def _c2_chunk(args):
+    first, count, N, three_boxes = args
+    return [make_instance(i, N, SEED0, bool(three_boxes)) for i in range(first, first + count)]
+
+
+def _spawn_chunks(kind, spans, extra):
+    """worker PROCESSES started from scratch (python -m ...scenarios KIND FIRST COUNT EXTRA... OUT), one per (first, count)
+    span: never a fork of a process that holds a HIP context, and no dependence on how the caller's __main__ was started.
+    Returns the unpickled results in span order."""
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    with tempfile.TemporaryDirectory() as tmp:
+        jobs = []
+        for j, (first, count) in enumerate(spans):
+            out = os.path.join(tmp, "%s_%d.pkl" % (kind, j))
+            jobs.append((out, subprocess.Popen([sys.executable, "-m", __name__, kind, str(first), str(count)] +
+                                               [str(e) for e in extra] + [out], cwd=root)))
+        for out, pr in jobs:
+            if pr.wait() != 0:
+                raise RuntimeError("scenario worker failed")
+            with open(out, "rb") as f:
+                res.append(pickle.load(f))
+    return res
+
+
+def make_batch(B, N=5, seed0=SEED0, three_boxes=False, first=0, procs=1):
+    """Arrays in the layout of include/obca_mpc.h for instances first .. first+B-1 (variant 4).  procs > 1 draws them in that
+    many worker processes (same result: every instance depends on its own seed only; default seed0 only)."""
+    if procs > 1 and B >= 4 * procs and seed0 == SEED0:
+        step = (B + procs - 1) // procs
+        spans = [(first + lo, min(step, B - lo)) for lo in range(0, B, step)]
+        ins = [q for part in _spawn_chunks("c2", spans, (N, int(three_boxes))) for q in part]
+    else:
+        ins = [make_instance(first + i, N, seed0, three_boxes) for i in range(B)]
     m = ins[0]["m"]
     M = sum(m)
     out = dict(
@@ -242,27 +277,12 @@ def make_batch_c3(B, N=20, first=0, gated=True, procs=1):
     many worker processes (same result -- every instance depends on its own seed only)."""
     ins, i = [], first
     if procs > 1:
-        # worker PROCESSES started from scratch (python -m ...scenarios): never a fork of a process that holds a HIP
-        # context, and no dependence on how the caller's __main__ was started
-        import pickle
-        import subprocess
-        import sys
-        import tempfile
         chunk = 64
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        with tempfile.TemporaryDirectory() as tmp:
-            while len(ins) < B:
-                jobs = []
-                for j in range(procs):
-                    out = os.path.join(tmp, "c3_%d.pkl" % j)
-                    jobs.append((out, subprocess.Popen([sys.executable, "-m", __name__, "c3", str(i + j * chunk), str(chunk),
-                                                        str(N), out], cwd=root)))
-                i += procs * chunk
-                for out, pr in jobs:
-                    if pr.wait() != 0:
-                        raise RuntimeError("scenario worker failed")
-                    with open(out, "rb") as f:
-                        ins += [q for _, q in pickle.load(f) if q["gated"] == gated]
+        while len(ins) < B:
+            parts = _spawn_chunks("c3", [(i + j * chunk, chunk) for j in range(procs)], (N,))
+            i += procs * chunk
+            for part in parts:
+                ins += [q for _, q in part if q["gated"] == gated]
         ins = ins[:B]
     while len(ins) < B:
         part = _c3_chunk((i, 1, N))
@@ -337,9 +357,12 @@ def make_world_c5(i, n_dyn=2, seed0=SEED0 + 2 * 10 ** 6):
     raise RuntimeError("could not draw a C5 world for seed %d" % (seed0 + i))
 
 
-if __name__ == "__main__":          # worker of make_batch_c3(procs > 1): python -m ...scenarios c3 FIRST COUNT N OUT
+if __name__ == "__main__":          # worker of make_batch / make_batch_c3 (procs > 1): python -m ...scenarios KIND FIRST COUNT N [..] OUT
     import pickle
     import sys
     if len(sys.argv) == 6 and sys.argv[1] == "c3":
         with open(sys.argv[5], "wb") as f:
             pickle.dump(_c3_chunk((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))), f)
+    elif len(sys.argv) == 7 and sys.argv[1] == "c2":
+        with open(sys.argv[6], "wb") as f:
+            pickle.dump(_c2_chunk((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))), f)
