@@ -22,6 +22,7 @@ struct obca_handle {
     int32_t M, n_max, R_max, inst_off;
     int32_t offm[OBCA_MAX_OBST + 1];
     int two_sided;                     // -1: where only the four-wavefront kernels fit (default), 0: never, 1: always
+    int64_t lds_pad;          // dev knob OBCA_LDS_PAD: bytes added to the one-wavefront kernels' LDS request (occupancy experiments)
     int64_t lds_bytes, lds_bytes_mw;   // one-wavefront kernels; four-wavefront kernels (+ the two-sided sweep's storage)
     int64_t lds_bytes_gm, gm_doubles;  // obca_ipm_kernel_gm: its LDS (O(N) blocks only) and its HBM workspace per workgroup
     int32_t inst_off_gm;
@@ -167,6 +168,8 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
         }
     }
     h->mode = 0;
+    h->lds_pad = 0;
+    if (const char* e = getenv("OBCA_LDS_PAD")) { const long v = atol(e); if (v > 0 && h->lds_bytes + v <= 64 * 1024) h->lds_pad = v; }
     h->two_sided = -1;
     if (const char* e = getenv("OBCA_TWO_SIDED")) { const int v = atoi(e); if (v >= -1 && v <= 1) h->two_sided = v; }
     if (const char* e = getenv("OBCA_MODE")) {
@@ -340,11 +343,11 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
             hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
                                (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2, L2);
         else if (h->R_max <= 256)
-            hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2, L2);
+            hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)(h->lds_bytes + h->lds_pad), (hipStream_t)hip_stream, L, L2, L2);
         else if (h->R_max <= 320)
-            hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2, L2);
+            hipLaunchKernelGGL(obca_ipm_kernel_r5, dim3(B), dim3(64), (size_t)(h->lds_bytes + h->lds_pad), (hipStream_t)hip_stream, L, L2, L2);
         else
-            hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)h->lds_bytes, (hipStream_t)hip_stream, L, L2, L2);
+            hipLaunchKernelGGL(obca_ipm_kernel_r6, dim3(B), dim3(64), (size_t)(h->lds_bytes + h->lds_pad), (hipStream_t)hip_stream, L, L2, L2);
     } else {
         if (!h->ws || !h->d_offm) {
             if (!h->ws && hipMalloc(&h->ws, sizeof(double) * (size_t)h->ws_doubles * h->ws_stride) != hipSuccess) { h->ws = nullptr; return OBCA_E_NOMEM; }
