@@ -271,6 +271,9 @@ int obca_rollouts_step(obca_rollouts* r, void* hip_stream);
  * its steps.  Mode 1 forces the lock-step launches. */
 int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_stream);
 int obca_rollouts_set_mode(obca_rollouts* r, int mode);
+/* The queue mode obca_rollouts_run uses (2, 1 or 0 as above).  2 is only offered where the device reports eight XCCs
+ * (hipDeviceAttributeNumberOfXccs; MI355X): the per-XCD queues identify an L2 by HW_REG_XCC_ID & 7.  Elsewhere the default is 1. */
+int obca_rollouts_queue_mode(const obca_rollouts* r);
 /* Diagnostic (-DOBCA_RO_STATS builds): per persistent workgroup [wait, work (10 ns units), items, end clock], n <= 16384 ints to host */
 int obca_rollouts_debug_stats(obca_rollouts* r, int32_t* out, int n);
 /* Test hook: runs ONLY the harness part of a step (obstacle advance, lidar gate, reference window, fixed-time preparation,

@@ -158,7 +158,7 @@ def test_c3_full_size_clearance_on_unique_seeds(gated):
     assert len(np.unique(b["x0"], axis=0)) == B
     r = _solve(b, N, cert=False)
     ok = (r["st"] == 0) | (r["st"] == 1)
-    assert ok.mean() > (0.965 if gated else 0.995)                 # measured: 99.56 % / 100 % (within 3 points)
+    assert ok.mean() > (0.97 if gated else 0.995)                  # measured: 99.79 % / 100 % (within 3 points)
     x, u, ts = r["x"][ok], r["u"][ok], r["ts"][ok]
     cl = kkt_check.min_clearance_boxes(x, sc.EGO, b["m"], b["A"][ok], b["b"][ok])
     assert cl.min() >= sc.DMIN - 1e-6, cl.min()

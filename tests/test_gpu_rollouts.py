@@ -81,13 +81,14 @@ def test_closed_loop_batch_properties():
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
     B = 256
     dr = DeviceRollouts([make_world_c5(i) for i in range(B)], N=5)
+    assert dr.queue_mode() == 2                                     # the default on MI355X: one work queue per XCD
     dr.run()
     o = {k: v.cpu().numpy() for k, v in dr.read().items()}
     torch.cuda.synchronize()
     steps, flags = o["steps"], o["flags"]
     assert np.all(flags != 0)                                       # every rollout ended: goal, cap or failure
     assert np.all(steps[flags == 2] == 30)
-    assert (flags != 3).mean() > 0.88                               # measured: 91 % here, 90.9 % of 4096 (bench.py closed_loop)
+    assert (flags != 3).mean() > 0.895                              # measured at 4096 rollouts: 92.3 % (316 stopped, 312 of them genuinely infeasible: profiles/r04_bench_classify_all.json)
     done = 0
     for i in range(B):
         k = steps[i]
@@ -236,6 +237,7 @@ def test_step_queue_schedule_equals_one_workgroup_per_rollout(monkeypatch):
         for env in ("2", "1", "0"):
             monkeypatch.setenv("OBCA_ROLLOUT_QUEUE", env)
             dr = DeviceRollouts(w, N=5, warm_start=warm) if warm else DeviceRollouts(w, N=5)
+            assert dr.queue_mode() == int(env)       # MI355X reports eight XCCs: the per-XCD queues are offered (and the default)
             dr.run()
             outs.append({k: v.cpu().numpy() for k, v in dr.read().items()})
             torch.cuda.synchronize()

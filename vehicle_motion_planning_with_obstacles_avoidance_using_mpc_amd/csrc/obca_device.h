@@ -84,6 +84,8 @@
 /* Fused closed loop: consecutive steps of one rollout per work item.  Measured on C5 (4096 rollouts x 30 steps, per-XCD
    queues): 1 / 2 / 3 / 5 / 6 / 10 steps -> 1.112 / 1.101 / 1.083 / 1.060 / 1.050 / 1.141 s: a longer item keeps the rollout's state
    warm in its CU and needs fewer hand-offs, a too long one leaves the end of the launch to a few workgroups. */
+/* XCDs of an MI355X (one L2 each): queues of the fused closed loop (obca_kernel.hip: rollout_fused_body) */
+#define OBCA_RO_XCDS 8
 #ifndef OBCA_RO_BLOCK
 #define OBCA_RO_BLOCK 6
 #endif

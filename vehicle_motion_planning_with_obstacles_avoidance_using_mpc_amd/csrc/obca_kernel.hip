@@ -2505,7 +2505,6 @@ __device__ __noinline__ long long ro_flag_sel(const rollout::Dev* D, int b) { re
 // sched[0]: next item of the global queue, sched[1]: abort flag (a wait that never ends must not hang the GPU),
 // sched[2 + b]: rounds done by rollout b, sched[2 + B + 16 q]: next item of queue q.
 #define OBCA_RO_SPIN_LIMIT (1 << 24)        /* x ~1 us of s_sleep: ~16 s */
-#define OBCA_RO_XCDS 8
 #define OBCA_GETREG_XCC_ID (20 | (0 << 6) | ((4 - 1) << 11))     /* hwreg(HW_REG_XCC_ID, 0, 4) */
 
 template <int RPL>

@@ -154,7 +154,12 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && cus > 0) r->n_slots = 4 * cus;
         else (void)hipGetLastError();
-        if (const char* e = getenv("OBCA_ROLLOUT_QUEUE")) { const int v = atoi(e); r->sched_mode = v < 0 || v > 2 ? 2 : v; }
+        // the per-XCD queues assume that HW_REG_XCC_ID & 7 names the L2 a workgroup runs under: true where the device reports
+        // eight XCCs (MI355X); on anything else -- or when the runtime cannot say -- hand-offs go through HBM (global queue)
+        int xccs = 0;
+        if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, d->device) != hipSuccess) { (void)hipGetLastError(); xccs = 0; }
+        if (xccs != OBCA_RO_XCDS) r->sched_mode = 1;
+        if (const char* e = getenv("OBCA_ROLLOUT_QUEUE")) { const int v = atoi(e); if (v >= 0 && v <= 2 && !(v == 2 && xccs != OBCA_RO_XCDS)) r->sched_mode = v; }
     }
     if (rc != OBCA_OK) { obca_rollouts_destroy(r); return rc; }
     *out = r;
@@ -326,6 +331,8 @@ extern "C" int obca_rollouts_debug_harness(obca_rollouts* r, int32_t k, double T
         !cp(b, D.b[g], sizeof(double) * B * N1 * Mg)) return OBCA_E_HIP;
     return hipStreamSynchronize(s) == hipSuccess ? OBCA_OK : OBCA_E_HIP;
 }
+
+extern "C" int obca_rollouts_queue_mode(const obca_rollouts* r) { return r ? r->sched_mode : OBCA_E_INVAL; }
 
 extern "C" int obca_rollouts_set_mode(obca_rollouts* r, int mode) {
     if (!r || mode < 0 || mode > 1) return OBCA_E_INVAL;

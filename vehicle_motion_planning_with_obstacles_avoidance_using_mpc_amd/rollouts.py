@@ -216,6 +216,10 @@ class DeviceRollouts:
         self.steps_enqueued += n
         return self
 
+    def queue_mode(self):
+        """2: one work queue per XCD (MI355X default), 1: one global queue, 0: one workgroup per rollout (obca_rollouts_queue_mode)"""
+        return int(self.lib.obca_rollouts_queue_mode(self._h))
+
     def set_mode(self, mode):
         """'fused' (default where it fits) | 'lockstep' (one launch per problem shape and step)"""
         self.mode = {"fused": 0, "lockstep": 1}.get(mode, mode)
