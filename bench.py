@@ -452,6 +452,8 @@ def main():
         ab = alg_bytes(N, M)
         achieved = ab * B / (kern_ms * 1e-3) / 1e9
         kname = "obca_ipm_kernel_r4" if solver_rows <= 256 else "obca_ipm_kernel_r5" if solver_rows <= 320 else "obca_ipm_kernel_r6"
+        if solver.specialised:          # the instantiation for this shape (csrc/obca_device.h: OBCA_SHAPES)
+            kname = "obca_ipm_kernel_s%d_%d_%d" % (N, len(batch["m"]), M)
         pmc = pmc_summary(kname, B, N, M)
         live = pmc if (pmc and not pmc["stale"]) else {}
         line = {

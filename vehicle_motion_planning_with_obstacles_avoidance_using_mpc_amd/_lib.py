@@ -48,7 +48,7 @@ class ObcaRolloutDims(ctypes.Structure):
 EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",
            "obca_set_profile_buffer", "obca_set_mode", "obca_set_two_sided_sweep", "obca_rollouts_create", "obca_rollouts_destroy", "obca_rollouts_debug_stats", "obca_rollouts_debug_harness",
            "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read", "obca_rollouts_run",
-           "obca_rollouts_set_mode", "obca_rollouts_queue_mode", "obca_astar_batch", "obca_astar_workspace_bytes", "obca_primal_size", "obca_set_warm_start",
+           "obca_rollouts_set_mode", "obca_rollouts_queue_mode", "obca_set_shape_specialisation", "obca_shape_is_specialised", "obca_astar_batch", "obca_astar_workspace_bytes", "obca_primal_size", "obca_set_warm_start",
            "obca_rollouts_set_warm_start", "obca_dual_size", "obca_set_certificate_buffers", "obca_rasterise_batch")
 
 OBCA_MAX_DYN = 4
@@ -125,6 +125,10 @@ def load():
     lib.obca_rollouts_debug_harness.restype = ctypes.c_int
     lib.obca_rollouts_set_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.obca_rollouts_set_mode.restype = ctypes.c_int
+    lib.obca_set_shape_specialisation.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.obca_set_shape_specialisation.restype = ctypes.c_int
+    lib.obca_shape_is_specialised.argtypes = [ctypes.c_void_p]
+    lib.obca_shape_is_specialised.restype = ctypes.c_int
     lib.obca_rollouts_queue_mode.argtypes = [ctypes.c_void_p]
     lib.obca_rollouts_queue_mode.restype = ctypes.c_int
     lib.obca_astar_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]

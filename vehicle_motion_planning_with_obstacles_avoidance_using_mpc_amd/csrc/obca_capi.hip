@@ -15,6 +15,12 @@ extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaL
 extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);          // four wavefronts per instance (obca_kernel_mw.hip)
 extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
 extern "C" __global__ void obca_ipm_kernel_gm(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);             // four wavefronts, rows in an HBM workspace
+// compile-time-shape instantiations of the one-wavefront kernel (csrc/obca_kernel_s*.hip; list: csrc/obca_device.h OBCA_SHAPES)
+#define OBCA_DECLARE_SHAPE_KERNEL(N_, O_, M_) extern "C" __global__ void obca_ipm_kernel_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
+OBCA_SHAPES(OBCA_DECLARE_SHAPE_KERNEL)
+#define OBCA_DECLARE_MW_SHAPE_KERNEL(N_, O_, M_) extern "C" __global__ void obca_ipm_kernel_mw_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
+OBCA_MW_SHAPES(OBCA_DECLARE_MW_SHAPE_KERNEL)
+typedef void (*obca_wave_kernel_t)(ObcaLaunch, ObcaLaunch, ObcaLaunch);
 extern "C" __global__ void obca_lpi_kernel(ObcaLaunch A, double* ws, unsigned long long stride, const int* offm, int ipw);
 
 struct obca_handle {
@@ -30,6 +36,9 @@ struct obca_handle {
     double* gm_ws;                     // allocated on first use: max_batch slices
     double* prof;
     int mode;                 /* 0 auto, 1 wave-per-instance (LDS), 2 lane-per-instance (HBM workspace), 3 four waves per instance */
+    obca_wave_kernel_t shape_kernel;   /* instantiation of the one-wavefront kernel for exactly this shape, or nullptr */
+    obca_wave_kernel_t shape_kernel_mw; /* likewise of the four-wavefront LDS kernel */
+    bool specialise;          /* use it (default; OBCA_SPECIALISE=0 / obca_set_shape_specialisation(h, 0): the generic kernels) */
     bool wave_ok;             /* the one-wavefront LDS kernel can hold this shape */
     bool mw_ok;               /* the four-wavefront LDS kernel can hold this shape */
     double* warm_z;           /* obca_set_warm_start */
@@ -56,30 +65,11 @@ bool dims_ok(const obca_dims* d) {
     return true;
 }
 
-// must mirror the carve-up in obca_kernel.hip
+// (the carve-up itself: csrc/obca_device.h: obca_shape_sizes, shared with the kernels)
 int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off) {
-    const int N1 = N + 1, np = N1 * nO;
-    n_max = N1 * (3 + M + 4 * nO) + 2 * N + 1;
-    R_max = 3 + 3 * N + 3 + 2 * N1 + 2 * N + 2 * N + 2 + 2 * np + N1 * M + N1 * 4 * nO;
-    int64_t t = 0;
-    auto take = [&](int64_t c) { t += (c + 1) & ~int64_t(1); };
-    take(n_max); take(n_max > 120 ? n_max : 120); take(5 * N1 + 1); take(n_max);   // x, dx (also FG / Mall / mall), gf (compact), bx
-    for (int i = 0; i < 5; ++i) take(R_max);                    // y, Einv, gh, Lb, Ub
-    take(3 * N1 + 3);                                           // dy of the soft rows
-    take(N1); take(N1); take(2 * np); take(N1); take(N1); take(2 * np);
-    take(2 * np); take(2 * np); take(2 * np);
-    take(N1 * M * 2); take(N1 * M); take(3 * N1);
-    take(36 * N1); take(8 * N1);                                // packed stage blocks, gradients
-    {
-        const int64_t nx = (n_max + 1) & ~1, nr = (R_max + 1) & ~1, ny = (int64_t)MW * 4 * np;
-        take(ny > nx + nr ? ny : nx + nr);                      // Y, shared with xt and tmp
-    }
-    take(36 * N1 > 12 * np ? 36 * N1 : 12 * np); take(6 * N1); take(12 * N1); take(2 * N1); take(9 * (N1 + 1));
-    take(32);                // lsv: iteration-level and line-search scalars
-    take(8);                 // offm
-    inst_off = (int)t;
-    take(OBCA_INST_DOUBLES);
-    return t;
+    const ObcaShapeSizes z = obca_shape_sizes(N, nO, M);
+    n_max = z.n_max; R_max = z.R_max; inst_off = z.inst_off;
+    return z.lds_doubles;
 }
 
 // the same for obca_ipm_kernel_gm (GM branch of the carve-up): LDS doubles, offset of the instance block, workspace doubles
@@ -168,6 +158,19 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
         }
     }
     h->mode = 0;
+    h->shape_kernel = nullptr;
+    h->shape_kernel_mw = nullptr;
+    h->specialise = true;
+#define OBCA_MATCH_MW_SHAPE_KERNEL(N_, O_, M_) if (d->N == N_ && d->n_obs == O_ && h->M == M_) h->shape_kernel_mw = obca_ipm_kernel_mw_s##N_##_##O_##_##M_;
+    OBCA_MW_SHAPES(OBCA_MATCH_MW_SHAPE_KERNEL)
+    if (h->shape_kernel_mw && h->mw_ok && h->lds_bytes_mw > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape_kernel_mw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_mw) != hipSuccess) {
+        (void)hipGetLastError();
+        h->shape_kernel_mw = nullptr;
+    }
+#define OBCA_MATCH_SHAPE_KERNEL(N_, O_, M_) if (d->N == N_ && d->n_obs == O_ && h->M == M_) h->shape_kernel = obca_ipm_kernel_s##N_##_##O_##_##M_;
+    OBCA_SHAPES(OBCA_MATCH_SHAPE_KERNEL)
+    if (const char* e = getenv("OBCA_SPECIALISE")) h->specialise = atoi(e) != 0;
     h->lds_pad = 0;
     if (const char* e = getenv("OBCA_LDS_PAD")) { const long v = atol(e); if (v > 0 && h->lds_bytes + v <= 64 * 1024) h->lds_pad = v; }
     h->two_sided = -1;
@@ -236,6 +239,19 @@ extern "C" int obca_set_certificate_buffers(obca_handle* h, double* z, double* y
     if (!h) return OBCA_E_INVAL;
     h->cert_z = z; h->cert_y = y;
     return OBCA_OK;
+}
+
+extern "C" int obca_set_shape_specialisation(obca_handle* h, int on) {
+    if (!h || on < 0 || on > 1) return OBCA_E_INVAL;
+    h->specialise = on != 0;
+    return OBCA_OK;
+}
+
+extern "C" int obca_shape_is_specialised(const obca_handle* h) {
+    if (!h) return OBCA_E_INVAL;
+    if (!h->specialise || h->mode == 2 || h->mode == 4) return 0;
+    const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
+    return mw ? (h->shape_kernel_mw ? 1 : 0) : (h->wave_ok && h->shape_kernel ? 1 : 0);
 }
 
 extern "C" int obca_set_two_sided_sweep(obca_handle* h, int on) {
@@ -339,9 +355,13 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     if (mw || !lane) {
         // the kernels run the further passes of the start ladder (penalty escalation, next starts) themselves, from their own copy of the descriptor
         ObcaLaunch L2 = L;
-        if (mw)
+        if (mw && h->shape_kernel_mw && h->specialise)
+            hipLaunchKernelGGL(h->shape_kernel_mw, dim3(B), dim3(256), (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2, L2);
+        else if (mw)
             hipLaunchKernelGGL(h->R_max <= 768 ? obca_ipm_kernel_mw_r3 : obca_ipm_kernel_mw_r5, dim3(B), dim3(256),
                                (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2, L2);
+        else if (h->shape_kernel && h->specialise)
+            hipLaunchKernelGGL(h->shape_kernel, dim3(B), dim3(64), (size_t)(h->lds_bytes + h->lds_pad), (hipStream_t)hip_stream, L, L2, L2);
         else if (h->R_max <= 256)
             hipLaunchKernelGGL(obca_ipm_kernel_r4, dim3(B), dim3(64), (size_t)(h->lds_bytes + h->lds_pad), (hipStream_t)hip_stream, L, L2, L2);
         else if (h->R_max <= 320)

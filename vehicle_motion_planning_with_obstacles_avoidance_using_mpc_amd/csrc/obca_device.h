@@ -90,6 +90,48 @@
 #define OBCA_RO_BLOCK 6
 #endif
 
+/* Sizes that follow from the problem shape (N, number of obstacles nO, half-space rows M) and the LDS carve-up of the
+   LDS-resident kernels (csrc/obca_kernel.hip: obca_ipm_body): ONE definition for the host (LDS request, kernel choice) and for
+   the kernels' compile-time-shape instantiations (OBCA_SHAPES below).  n_max: variables, R_max: elastic rows (the largest
+   over the three variants), inst_off: offset of the per-instance constant block, lds_doubles: doubles of dynamic LDS. */
+struct ObcaShapeSizes { int n_max, R_max, inst_off; long long lds_doubles; };
+constexpr long long obca_even(long long c) { return (c + 1) & ~1ll; }
+constexpr ObcaShapeSizes obca_shape_sizes(int N, int nO, int M) {
+    const int N1 = N + 1, np = N1 * nO, MW = OBCA_MAX_EDGES + 6;
+    const int n_max = N1 * (3 + M + 4 * nO) + 2 * N + 1;
+    const int R_max = 3 + 3 * N + 3 + 2 * N1 + 2 * N + 2 * N + 2 + 2 * np + N1 * M + N1 * 4 * nO;
+    long long t = 0;
+    t += obca_even(n_max) + obca_even(n_max > 120 ? n_max : 120) + obca_even(5 * N1 + 1) + obca_even(n_max);   // x, dx (also FG / Mall / mall), gf (compact), bx
+    t += 5 * obca_even(R_max);                                                                               // y, Einv, gh, Lb, Ub
+    t += obca_even(3 * N1 + 3);                                                                              // dy of the soft rows
+    t += 4 * obca_even(N1) + 2 * obca_even(2 * np);                                                          // ct, st, ctt, stt; cc, cct
+    t += 3 * obca_even(2 * np);                                                                              // nu, dnu, crot
+    t += obca_even(N1 * M * 2) + obca_even(N1 * M) + obca_even(3 * N1);                                      // Aobs, bobs, xref
+    t += obca_even(36 * N1) + obca_even(8 * N1);                                                             // packed stage blocks, gradients
+    {
+        const long long nx = obca_even(n_max), nr = obca_even(R_max), ny = (long long)MW * 4 * np;
+        t += obca_even(ny > nx + nr ? ny : nx + nr);                                                         // Y, shared with xt and tmp
+    }
+    t += obca_even(36 * N1 > 12 * np ? 36 * N1 : 12 * np) + obca_even(6 * N1) + obca_even(12 * N1) + obca_even(2 * N1) + obca_even(9 * (N1 + 1));   // Pk (also Sloc), qk, Kk, kapk, Mik
+    t += obca_even(32) + obca_even(8);                                                                       // lsv, offm
+    const int inst_off = (int)t;
+    t += OBCA_INST_DOUBLES;
+    return ObcaShapeSizes{n_max, R_max, inst_off, t};
+}
+/* Compile-time-shape instantiations of the one-wavefront kernel: X(N, nO, M).  With the shape known to the compiler every LDS
+   offset is an immediate, the stage loops and the index arithmetic (divisions by nO, M, 4 nO, the stage stride) fold, and the
+   scalar registers that held ~35 array offsets and the layout are free: measured on C2 29.7 -> 26.6 ms per 8192 solves, every
+   output word equal to the generic kernel's (tests/test_gpu_shapes.py).  Listed: the configurations the reference's closed-loop
+   driver produces -- N_free = N_fix = 5 (the GIF's setting, BASELINE) or 6 (src/closed_loop.py:66-67 as checked in), three
+   static obstacles with 1 + 4 + 1 rows (two walls, one box: demo1 / demo8) plus 0, 1 or 2 sensed moving rectangles of four
+   rows each.  Any other shape runs the generic kernels; OBCA_SPECIALISE=0 / obca_set_shape_specialisation(h, 0) forces them. */
+#define OBCA_SHAPES(X) X(5, 3, 6) X(5, 4, 10) X(5, 5, 14) X(6, 3, 6) X(6, 4, 10) X(6, 5, 14)
+/* ... and of the fused closed-loop kernel: X(N, nS, MS) = the three shapes (N, nS + g, MS + 4 g), g = 0, 1, 2 sensed rectangles */
+#define OBCA_FAMILIES(X) X(5, 3, 6) X(6, 3, 6)
+/* ... and of the four-wavefront LDS kernels: the two halves of BASELINE.json's configs[2] (N = 20: free-time against the three
+   static obstacles, gated fixed-time against five) */
+#define OBCA_MW_SHAPES(X) X(20, 3, 6) X(20, 5, 14)
+
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
 /* order: obca_params.start_order (validated); nstarts: 1 (single_start) or 3; patience / retry_iter: resolved (> 0) */
 struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, order, nstarts, patience, retry_iter, pad_; };

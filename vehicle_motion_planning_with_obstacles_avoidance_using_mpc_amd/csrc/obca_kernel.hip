@@ -61,8 +61,9 @@ __device__ __noinline__ SinCos dsincos(double x) { SinCos r; r.s = sin(x); r.c =
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    // (every lane of these patterns has a source lane: no `old` value is needed -- passing one cost two v_mov per move)
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ double lane_read(double v, int l) {
@@ -1582,7 +1583,28 @@ struct ObcaHead {
 
 typedef const __attribute__((address_space(4))) ObcaLaunch ObcaLaunchConst;   // descriptor in HBM, read through the scalar cache
 
-template <int RPL, bool FROM_MEMORY = false, class DESC = const ObcaLaunch>
+// The problem shape as the body sees it: ShapeAny -- read from the launch descriptor (any shape the kernel's limits allow);
+// ShapeIs<N, nO, M> -- compile-time constants (csrc/obca_device.h: OBCA_SHAPES): same code, same arithmetic, same results,
+// but every LDS offset, loop bound and index division folds.  The host only launches an instantiation for its own shape.
+struct ShapeAny { static constexpr bool fixed = false; static constexpr int N = 0, nO = 0, M = 0, n_max = 0, R_max = 0, inst_off = 0; };
+// FT: the fixed-time variants only (the closed loop's groups with sensed boxes: their layouts have three rows less than the
+// free-time layout the handle sizes for, csrc/obca_rollout.hip)
+template <int N_, int NO_, int M_, bool FT = false>
+struct ShapeIs {
+    static constexpr bool fixed = true;
+    static constexpr int N = N_, nO = NO_, M = M_;
+    static constexpr int n_max = obca_shape_sizes(N_, NO_, M_).n_max, R_max = obca_shape_sizes(N_, NO_, M_).R_max - (FT ? 3 : 0),
+                         inst_off = obca_shape_sizes(N_, NO_, M_).inst_off;
+#if OBCA_NT == 64
+    static constexpr int RPL = R_max <= 256 ? 4 : R_max <= 320 ? 5 : 6;       // rows per lane, as obca_solve_batch picks _r4 / _r5 / _r6
+    static_assert(R_max <= 384, "shape beyond the one-wavefront kernels");
+#else
+    static constexpr int RPL = R_max <= 768 ? 3 : -5;                         // four wavefronts: as _mw_r3 / _mw_r5
+    static_assert(R_max <= 1280, "shape beyond the four-wavefront LDS kernels");
+#endif
+};
+
+template <int RPL, bool FROM_MEMORY = false, class DESC = const ObcaLaunch, class SHAPE = ShapeAny>
 __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const bool first) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
@@ -1597,6 +1619,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         A.prof = uni<U>(Ain.prof); A.warm_z = uni<U>(Ain.warm_z); A.warm_use = uni<U>(Ain.warm_use); A.warm_mu = uni<U>(Ain.warm_mu);
         A.cert_z = uni<U>(Ain.cert_z); A.cert_y = uni<U>(Ain.cert_y); A.soc_ws = uni<U>(Ain.soc_ws);
         A.gm_ws = Ain.gm_ws; A.gm_stride = Ain.gm_stride;
+        if constexpr (SHAPE::fixed) {
+            A.N = SHAPE::N; A.nO = SHAPE::nO; A.M = SHAPE::M; A.n_max = SHAPE::n_max; A.R_max = SHAPE::R_max; A.inst_off = SHAPE::inst_off;
+        }
     }
     if (inst >= A.B) return;
     if (A.variant[inst] == 0) {                      // masked out by the caller (device-side closed loop)
@@ -2352,7 +2377,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         // the output side of the descriptor is read again here instead of being carried through the solve in registers
         __asm__ volatile("" ::: "memory");
         constexpr bool U = FROM_MEMORY;
-        A.n_max = uni<U>(Ain.n_max); A.R_max = uni<U>(Ain.R_max);
+        if constexpr (!SHAPE::fixed) { A.n_max = uni<U>(Ain.n_max); A.R_max = uni<U>(Ain.R_max); }
         A.xopt = uni<U>(Ain.xopt); A.uopt = uni<U>(Ain.uopt); A.ts_opt = uni<U>(Ain.ts_opt); A.status = uni<U>(Ain.status);
         A.iters = uni<U>(Ain.iters); A.info = uni<U>(Ain.info); A.warm_z = uni<U>(Ain.warm_z);
         A.cert_z = uni<U>(Ain.cert_z); A.cert_y = uni<U>(Ain.cert_y);
@@ -2407,47 +2432,47 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
 //          gated 300 against 321 ms per 2048 solves.
 // (Measured and rejected: the hot copy straight + a loop over ONE cold copy, or the cold passes in an out-of-line function -- the
 // hot copy then needs 48-240 B of scratch, or the callee 1.9 KB for its callee-saved registers.)
-template <int RPL, bool LOOP, class DESC>
+template <int RPL, bool LOOP, class DESC, class SHAPE = ShapeAny>
 __device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
     const int inst = blockIdx.x;
     if constexpr (LOOP) {
         if (inst >= A.B) return;
 #pragma clang loop unroll(disable)
         for (int pass = 0; pass < OBCA_MAX_PASSES; ++pass) {
-            obca_ipm_body<RPL, false, DESC>(A, inst, pass == 0);
+            obca_ipm_body<RPL, false, DESC, SHAPE>(A, inst, pass == 0);
             __syncthreads();                                        // status written by thread 0 of this workgroup
             const int st = A.status[inst];
             if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing (more) to recover
         }
     } else {
         static_assert(OBCA_MAX_PASSES == 6, "one inlined copy of the body per pass");
-        obca_ipm_body<RPL, false, DESC>(A, inst, true);
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A, inst, true);
         if (inst >= A.B) return;
         __syncthreads();                                            // status written by thread 0 of this workgroup
         {
             const int st = A2.status[inst];
             if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing to recover
         }
-        obca_ipm_body<RPL, false, DESC>(A2, inst, false);
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A2, inst, false);
         __syncthreads();
-        obca_ipm_body<RPL, false, DESC>(A3, inst, false);
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A3, inst, false);
         __syncthreads();
-        obca_ipm_body<RPL, false, DESC>(A2, inst, false);
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A2, inst, false);
         __syncthreads();
-        obca_ipm_body<RPL, false, DESC>(A3, inst, false);
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A3, inst, false);
         __syncthreads();
-        obca_ipm_body<RPL, false, DESC>(A2, inst, false);
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A2, inst, false);
     }
 }
 // KARG: the descriptors are read through the kernarg segment pointer (constant address space) instead of the by-value
 // parameters.  Which form leaves the allocator more room differs from kernel to kernel (tools/kernel_resources.py).
-template <int RPL, bool LOOP, bool KARG = false>
+template <int RPL, bool LOOP, bool KARG = false, class SHAPE = ShapeAny>
 __device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const ObcaLaunch& A2, const ObcaLaunch& A3) {
     if constexpr (KARG) {
         ObcaLaunchConst* Ap = (ObcaLaunchConst*)__builtin_amdgcn_kernarg_segment_ptr();
-        solve_passes<RPL, LOOP, ObcaLaunchConst>(Ap[0], Ap[1], Ap[2]);
+        solve_passes<RPL, LOOP, ObcaLaunchConst, SHAPE>(Ap[0], Ap[1], Ap[2]);
     } else {
-        solve_passes<RPL, LOOP, const ObcaLaunch>(A, A2, A3);
+        solve_passes<RPL, LOOP, const ObcaLaunch, SHAPE>(A, A2, A3);
     }
 }
 
@@ -2463,10 +2488,21 @@ __device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const
 #ifndef OBCA_LOOP_GM
 #define OBCA_LOOP_GM true
 #endif
-#if OBCA_NT == 64
+#if OBCA_NT == 64 && defined(OBCA_TU_SHAPE)
+// A translation unit of compile-time-shape instantiations (csrc/obca_kernel_s*.hip define OBCA_TU_SHAPE(X) as X(N, nO, M) ...
+// and include this file): only those kernels, none of the generic ones.  obca_ipm_kernel_s<N>_<nO>_<M>.
+#define OBCA_DEFINE_SHAPE_KERNEL(N_, O_, M_)                                                                                   \
+    extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { \
+        using SH = ShapeIs<N_, O_, M_>;                                                                                        \
+        solve_with_escalation<SH::RPL, true, false, SH>(A, A2, A3);                                                           \
+    }
+OBCA_TU_SHAPE(OBCA_DEFINE_SHAPE_KERNEL)
+#elif OBCA_NT == 64
+#ifndef OBCA_TU_FAMILY
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<4, OBCA_LOOP_R4>(A, A2, A3); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5, OBCA_LOOP_R56>(A, A2, A3); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<6, OBCA_LOOP_R56>(A, A2, A3); }
+#endif
 
 // ================================================================== fused closed loop
 // One wavefront runs one step of one rollout at a time: lane 0 runs the harness of csrc/obca_rollout_core.h around
@@ -2507,7 +2543,49 @@ __device__ __noinline__ long long ro_flag_sel(const rollout::Dev* D, int b) { re
 #define OBCA_RO_SPIN_LIMIT (1 << 24)        /* x ~1 us of s_sleep: ~16 s */
 #define OBCA_GETREG_XCC_ID (20 | (0 << 6) | ((4 - 1) << 11))     /* hwreg(HW_REG_XCC_ID, 0, 4) */
 
-template <int RPL>
+// The shapes of a closed loop as the fused kernel sees them: FamilyAny -- whatever the descriptors say (one body, RPL rows per
+// lane for all groups); FamilyIs<N, nS, MS> -- N_free = N_fix = N, nS static obstacles with MS rows, group g = 0, 1, 2 sensed
+// rectangles: the three shapes (N, nS + g, MS + 4 g) as compile-time constants (csrc/obca_device.h: OBCA_SHAPES), each with
+// its own inlined body and its own number of rows per lane.  Same words as the generic kernel (tests/test_gpu_shapes.py).
+struct FamilyAny { static constexpr bool fixed = false; };
+template <int N_, int NS_, int MS_>
+struct FamilyIs {
+    static constexpr bool fixed = true;
+    using S0 = ShapeIs<N_, NS_, MS_>;
+    using S1 = ShapeIs<N_, NS_ + 1, MS_ + 4, true>;
+    using S2 = ShapeIs<N_, NS_ + 2, MS_ + 8, true>;
+};
+
+// The solves of one step of rollout b, group g (= sensed rectangles).  Attempts 0 .. P-1 (P = OBCA_MAX_PASSES): the passes of the
+// solve (the start ladder -- the body returns at once where nothing is left to do); attempts P .. 2P-1: the same for obca_mpc8
+// where obca_mpc6 failed (src/closed_loop.py:393-398).  One call site: the body is inlined once per instantiation.
+template <int RPL, class SHAPE>
+__device__ __forceinline__ void ro_solve_step(const rollout::Dev& D, const ObcaLaunch* launches, const int g, const int b, int* ro_msg) {
+    const int lane = threadIdx.x;
+    for (int attempt = 0; attempt < 2 * OBCA_MAX_PASSES; ++attempt) {
+        const ObcaLaunch* Lp = launches + g;
+        if (attempt >= OBCA_MAX_PASSES) {
+            if (g == 0) break;
+            if (attempt == OBCA_MAX_PASSES) {
+                if (lane == 0) ro_msg[0] = ro_retry(&D, g, b);
+                __syncthreads();
+                const int v8 = ro_msg[0];
+                __syncthreads();
+                if (v8 != 8) break;
+            }
+            Lp = launches + g + rollout::MAX_GROUPS;
+        }
+        obca_ipm_body<RPL, false, ObcaLaunchConst, SHAPE>(*(ObcaLaunchConst*)Lp, b, attempt == 0 || attempt == OBCA_MAX_PASSES);
+        __syncthreads();
+        {   // nothing (more) to recover: on to obca_mpc8's turn, or out
+            const int st = __builtin_amdgcn_readfirstlane(((ObcaLaunchConst*)Lp)->status[b]);
+            if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC)
+                attempt = (attempt < OBCA_MAX_PASSES ? OBCA_MAX_PASSES : 2 * OBCA_MAX_PASSES) - 1;
+        }
+    }
+}
+
+template <int RPL, class FAM = FamilyAny>
 __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
     const int lane = threadIdx.x;
     __shared__ int ro_msg[3];
@@ -2578,29 +2656,13 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
         const int g = __builtin_amdgcn_readfirstlane(ro_msg[1]);     // wave-uniform: the descriptor is read with scalar loads
         __syncthreads();
         if (running) {
-            // attempts 0 .. P-1 (P = OBCA_MAX_PASSES): the passes of the solve (the start ladder -- the body returns at once where
-            // nothing is left to do); attempts P .. 2P-1: the same for obca_mpc8 where obca_mpc6 failed
-            // (src/closed_loop.py:393-398).  One call site: the body is inlined once.
-            for (int attempt = 0; attempt < 2 * OBCA_MAX_PASSES; ++attempt) {
-                const ObcaLaunch* Lp = launches + g;
-                if (attempt >= OBCA_MAX_PASSES) {
-                    if (g == 0) break;
-                    if (attempt == OBCA_MAX_PASSES) {
-                        if (lane == 0) ro_msg[0] = ro_retry(&D, g, b);
-                        __syncthreads();
-                        const int v8 = ro_msg[0];
-                        __syncthreads();
-                        if (v8 != 8) break;
-                    }
-                    Lp = launches + g + rollout::MAX_GROUPS;
-                }
-                obca_ipm_body<RPL, false, ObcaLaunchConst>(*(ObcaLaunchConst*)Lp, b, attempt == 0 || attempt == OBCA_MAX_PASSES);
-                __syncthreads();
-                {   // nothing (more) to recover: on to obca_mpc8's turn, or out
-                    const int st = __builtin_amdgcn_readfirstlane(((ObcaLaunchConst*)Lp)->status[b]);
-                    if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC)
-                        attempt = (attempt < OBCA_MAX_PASSES ? OBCA_MAX_PASSES : 2 * OBCA_MAX_PASSES) - 1;
-                }
+            // (family instantiations: one copy of the attempt loop per shape -- the branch on the group is taken once per step)
+            if constexpr (FAM::fixed) {
+                if (g == 0) ro_solve_step<FAM::S0::RPL, typename FAM::S0>(D, launches, g, b, ro_msg);
+                else if (g == 1) ro_solve_step<FAM::S1::RPL, typename FAM::S1>(D, launches, g, b, ro_msg);
+                else ro_solve_step<FAM::S2::RPL, typename FAM::S2>(D, launches, g, b, ro_msg);
+            } else {
+                ro_solve_step<RPL, ShapeAny>(D, launches, g, b, ro_msg);
             }
             if (lane == 0) ro_finish(&D, b);
             __syncthreads();
@@ -2632,6 +2694,16 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
 #endif
 }
 
+#ifdef OBCA_TU_FAMILY
+// A translation unit of one closed-loop family (csrc/obca_kernel_f*.hip define OBCA_TU_FAMILY(X) as X(N, nS, MS) and include this
+// file): obca_rollout_fused_kernel_f<N>_<nS>_<MS>, nothing else.
+#define OBCA_DEFINE_FAMILY_KERNEL(N_, S_, M_)                                                                                  \
+    extern "C" __global__ void __launch_bounds__(64)                                                                           \
+    obca_rollout_fused_kernel_f##N_##_##S_##_##M_(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) { \
+        rollout_fused_body<0, FamilyIs<N_, S_, M_>>(*Dp, launches, n_steps, sched, qmode);                                     \
+    }
+OBCA_TU_FAMILY(OBCA_DEFINE_FAMILY_KERNEL)
+#else
 // _r4: every shape of the rollout has <= 256 rows (static obstacles only at N=5); _r6: <= 384 rows
 extern "C" __global__ void __launch_bounds__(64)
 obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
@@ -2645,7 +2717,16 @@ extern "C" __global__ void __launch_bounds__(64)
 obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
     rollout_fused_body<6>(*Dp, launches, n_steps, sched, qmode);
 }
+#endif
 
+#elif defined(OBCA_TU_SHAPE)
+// four wavefronts per instance, shape known at compile time: obca_ipm_kernel_mw_s<N>_<nO>_<M> (csrc/obca_kernel_mw_s*.hip)
+#define OBCA_DEFINE_MW_SHAPE_KERNEL(N_, O_, M_)                                                                                \
+    extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { \
+        using SH = ShapeIs<N_, O_, M_>;                                                                                        \
+        solve_with_escalation<SH::RPL, OBCA_LOOP_MW, true, SH>(A, A2, A3);                                                    \
+    }
+OBCA_TU_SHAPE(OBCA_DEFINE_MW_SHAPE_KERNEL)
 #else
 #ifndef OBCA_KARG_R3
 #define OBCA_KARG_R3 true

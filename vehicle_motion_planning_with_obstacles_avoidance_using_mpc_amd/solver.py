@@ -120,6 +120,16 @@ class BatchSolver:
         None / -1 = default (only where the one-wavefront kernels cannot run the shape), False / True = never / always"""
         _lib.check(self.lib.obca_set_two_sided_sweep(self._h, -1 if on is None else int(on)))
 
+    def set_shape_specialisation(self, on):
+        """use (default) or bypass the compile-time-shape instantiation of the one-wavefront kernel this handle's shape may
+        have (include/obca_mpc.h: obca_set_shape_specialisation); results are the same words either way"""
+        _lib.check(self.lib.obca_set_shape_specialisation(self._h, 1 if on else 0))
+
+    @property
+    def specialised(self):
+        """True if launches of this handle run a compile-time-shape instantiation (csrc/obca_device.h: OBCA_SHAPES)"""
+        return self.lib.obca_shape_is_specialised(self._h) == 1
+
     def enable_certificates(self, on=True):
         """Keep the final primal vector and multipliers of every solve (include/obca_mpc.h, obca_set_certificate_buffers):
         after a solve ``self.cert_z[:B]`` is [B, primal_size] and ``self.cert_y[:B]`` is [B, dual_size]."""
