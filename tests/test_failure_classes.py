@@ -1,4 +1,4 @@
-"""Failure classification (tools/failure_study.py holds the full study, DESIGN.md section 2 the table).
+"""Failure classification (the machinery is tests/independent.py, which bench.py also runs at full size).
 
 An instance on which the product's interior-point method does not return feas=True is handed to an independent solver
 (SciPy SLSQP on the reference-pinned model, three starts): a feasible point proves the instance feasible => "solver
@@ -6,20 +6,13 @@ failure"; none found => "no feasible point found".  On the headline workload (co
 must stay below 1 %.  For the fixed-time problems the share is NOT small (cold start from zeros into a non-convex
 feasibility problem) -- what is asserted there is what the reference's driver relies on: every obca_mpc6 failure
 is answered by obca_mpc8 on the same inputs (src/closed_loop.py:393-398), and that recovers them."""
-import os
-import sys
-
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-
-from tests import kkt_check, native_build  # noqa: E402
+from tests import independent, kkt_check, native_build  # noqa: E402
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc  # noqa: E402
 
 
 def test_c2_solver_failure_share_is_below_one_percent():
-    import failure_study as fs
     B, N = 768, 5
     b = sc.make_batch(B, N)
     o = native_build.lpi_solve(b["variant"], N, b["m"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], cert=True)
@@ -27,8 +20,8 @@ def test_c2_solver_failure_share_is_below_one_percent():
     assert len(bad) <= 0.01 * B                                   # (all failures together, whatever their class)
     solver_failures = 0
     for i in bad[:4]:
-        r = fs.independent(kkt_check.problem_of(b, i, N), o["z"][i], maxiter=200)
-        solver_failures += r["viol"] <= 1e-6
+        r = independent.classify((kkt_check.problem_of(b, i, N), o["z"][i], int(i)))
+        solver_failures += r["feasible_point_found"]
     assert solver_failures <= 0.01 * B
 
 

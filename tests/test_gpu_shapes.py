@@ -61,24 +61,6 @@ def test_other_shapes_run_the_generic_kernels():
     s.close()
 
 
-@pytest.mark.parametrize("N", [5, 6])
-def test_closed_loop_family_kernel_returns_the_generic_kernels_words(monkeypatch, N):
-    """the fused closed-loop kernel instantiated for the family (N, 3 static obstacles with 6 rows, 0 / 1 / 2 sensed rectangles) against
-    the generic fused kernel (OBCA_SPECIALISE=0): every word of every output of 512 C5 rollouts, all 30 steps"""
-    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
-    w = pack_worlds([sc.make_world_c5(i, n_dyn=2) for i in range(512)])
-    outs = []
-    for env in ("1", "0"):
-        monkeypatch.setenv("OBCA_SPECIALISE", env)
-        dr = DeviceRollouts(w, N=N)
-        dr.run()
-        outs.append({k: v.cpu().numpy() for k, v in dr.read().items()})
-        torch.cuda.synchronize()
-    for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k]), (N, k)
-    assert outs[0]["steps"].sum() > 0.8 * 512 * 30
-
-
 @pytest.mark.parametrize("gated", [False, True])
 def test_four_wavefront_instantiations_return_the_generic_kernels_words(gated):
     """OBCA_MW_SHAPES: the two halves of BASELINE configs[2] at N = 20 (694 / 1114 rows, four wavefronts per instance, two-sided

@@ -2498,11 +2498,9 @@ __device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const
     }
 OBCA_TU_SHAPE(OBCA_DEFINE_SHAPE_KERNEL)
 #elif OBCA_NT == 64
-#ifndef OBCA_TU_FAMILY
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<4, OBCA_LOOP_R4>(A, A2, A3); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5, OBCA_LOOP_R56>(A, A2, A3); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<6, OBCA_LOOP_R56>(A, A2, A3); }
-#endif
 
 // ================================================================== fused closed loop
 // One wavefront runs one step of one rollout at a time: lane 0 runs the harness of csrc/obca_rollout_core.h around
@@ -2543,22 +2541,9 @@ __device__ __noinline__ long long ro_flag_sel(const rollout::Dev* D, int b) { re
 #define OBCA_RO_SPIN_LIMIT (1 << 24)        /* x ~1 us of s_sleep: ~16 s */
 #define OBCA_GETREG_XCC_ID (20 | (0 << 6) | ((4 - 1) << 11))     /* hwreg(HW_REG_XCC_ID, 0, 4) */
 
-// The shapes of a closed loop as the fused kernel sees them: FamilyAny -- whatever the descriptors say (one body, RPL rows per
-// lane for all groups); FamilyIs<N, nS, MS> -- N_free = N_fix = N, nS static obstacles with MS rows, group g = 0, 1, 2 sensed
-// rectangles: the three shapes (N, nS + g, MS + 4 g) as compile-time constants (csrc/obca_device.h: OBCA_SHAPES), each with
-// its own inlined body and its own number of rows per lane.  Same words as the generic kernel (tests/test_gpu_shapes.py).
-struct FamilyAny { static constexpr bool fixed = false; };
-template <int N_, int NS_, int MS_>
-struct FamilyIs {
-    static constexpr bool fixed = true;
-    using S0 = ShapeIs<N_, NS_, MS_>;
-    using S1 = ShapeIs<N_, NS_ + 1, MS_ + 4, true>;
-    using S2 = ShapeIs<N_, NS_ + 2, MS_ + 8, true>;
-};
-
 // The solves of one step of rollout b, group g (= sensed rectangles).  Attempts 0 .. P-1 (P = OBCA_MAX_PASSES): the passes of the
 // solve (the start ladder -- the body returns at once where nothing is left to do); attempts P .. 2P-1: the same for obca_mpc8
-// where obca_mpc6 failed (src/closed_loop.py:393-398).  One call site: the body is inlined once per instantiation.
+// where obca_mpc6 failed (src/closed_loop.py:393-398).  One call site: the body is inlined once.
 template <int RPL, class SHAPE>
 __device__ __forceinline__ void ro_solve_step(const rollout::Dev& D, const ObcaLaunch* launches, const int g, const int b, int* ro_msg) {
     const int lane = threadIdx.x;
@@ -2585,7 +2570,7 @@ __device__ __forceinline__ void ro_solve_step(const rollout::Dev& D, const ObcaL
     }
 }
 
-template <int RPL, class FAM = FamilyAny>
+template <int RPL>
 __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
     const int lane = threadIdx.x;
     __shared__ int ro_msg[3];
@@ -2656,14 +2641,7 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
         const int g = __builtin_amdgcn_readfirstlane(ro_msg[1]);     // wave-uniform: the descriptor is read with scalar loads
         __syncthreads();
         if (running) {
-            // (family instantiations: one copy of the attempt loop per shape -- the branch on the group is taken once per step)
-            if constexpr (FAM::fixed) {
-                if (g == 0) ro_solve_step<FAM::S0::RPL, typename FAM::S0>(D, launches, g, b, ro_msg);
-                else if (g == 1) ro_solve_step<FAM::S1::RPL, typename FAM::S1>(D, launches, g, b, ro_msg);
-                else ro_solve_step<FAM::S2::RPL, typename FAM::S2>(D, launches, g, b, ro_msg);
-            } else {
-                ro_solve_step<RPL, ShapeAny>(D, launches, g, b, ro_msg);
-            }
+            ro_solve_step<RPL, ShapeAny>(D, launches, g, b, ro_msg);
             if (lane == 0) ro_finish(&D, b);
             __syncthreads();
         }
@@ -2694,16 +2672,6 @@ __device__ __forceinline__ void rollout_fused_body(const rollout::Dev& D, const 
 #endif
 }
 
-#ifdef OBCA_TU_FAMILY
-// A translation unit of one closed-loop family (csrc/obca_kernel_f*.hip define OBCA_TU_FAMILY(X) as X(N, nS, MS) and include this
-// file): obca_rollout_fused_kernel_f<N>_<nS>_<MS>, nothing else.
-#define OBCA_DEFINE_FAMILY_KERNEL(N_, S_, M_)                                                                                  \
-    extern "C" __global__ void __launch_bounds__(64)                                                                           \
-    obca_rollout_fused_kernel_f##N_##_##S_##_##M_(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) { \
-        rollout_fused_body<0, FamilyIs<N_, S_, M_>>(*Dp, launches, n_steps, sched, qmode);                                     \
-    }
-OBCA_TU_FAMILY(OBCA_DEFINE_FAMILY_KERNEL)
-#else
 // _r4: every shape of the rollout has <= 256 rows (static obstacles only at N=5); _r6: <= 384 rows
 extern "C" __global__ void __launch_bounds__(64)
 obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
@@ -2717,10 +2685,11 @@ extern "C" __global__ void __launch_bounds__(64)
 obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode) {
     rollout_fused_body<6>(*Dp, launches, n_steps, sched, qmode);
 }
-#endif
 
 #elif defined(OBCA_TU_SHAPE)
-// four wavefronts per instance, shape known at compile time: obca_ipm_kernel_mw_s<N>_<nO>_<M> (csrc/obca_kernel_mw_s*.hip)
+// four wavefronts per instance, shape known at compile time: obca_ipm_kernel_mw_s<N>_<nO>_<M> (csrc/obca_kernel_mw_s*.hip).
+// Straight-line passes and descriptors through the kernarg pointer, as measured for _mw_r3 / _mw_r5 (the other three combinations
+// of the two need 128 / 304 / 320 B of scratch for (20, 5, 14) instead of 80).
 #define OBCA_DEFINE_MW_SHAPE_KERNEL(N_, O_, M_)                                                                                \
     extern "C" __global__ void __launch_bounds__(OBCA_NT) obca_ipm_kernel_mw_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { \
         using SH = ShapeIs<N_, O_, M_>;                                                                                        \

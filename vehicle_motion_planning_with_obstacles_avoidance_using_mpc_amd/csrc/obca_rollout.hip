@@ -11,10 +11,6 @@
 extern "C" __global__ void obca_rollout_fused_kernel_r4(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode);
 extern "C" __global__ void obca_rollout_fused_kernel_r5(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode);
 extern "C" __global__ void obca_rollout_fused_kernel_r6(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode);
-// compile-time-shape families of the fused kernel (csrc/obca_kernel_f*.hip; list: csrc/obca_device.h OBCA_FAMILIES)
-#define OBCA_DECLARE_FAMILY_KERNEL(N_, S_, M_) extern "C" __global__ void obca_rollout_fused_kernel_f##N_##_##S_##_##M_(const rollout::Dev* Dp, const ObcaLaunch* launches, int n_steps, int* sched, int qmode);
-OBCA_FAMILIES(OBCA_DECLARE_FAMILY_KERNEL)
-typedef void (*obca_fused_kernel_t)(const rollout::Dev*, const ObcaLaunch*, int, int*, int);
 
 namespace {
 
@@ -58,7 +54,6 @@ struct obca_rollouts {
     bool queue_ran;           /* the last obca_rollouts_run used the device-side work queue (its abort flag is then checked by read) */
     int32_t rows_max;
     int64_t lds_max;
-    obca_fused_kernel_t family_kernel;   /* the fused kernel instantiated for exactly this rollout's shapes, or nullptr (OBCA_SPECIALISE=0: never) */
     int mode;                 /* 0 auto (fused when every shape fits the wave kernel), 1 lock-step launches */
     double warm_mu;           /* > 0: warm start enabled */
     // constants owned by the handle (copied at reset so the caller's buffers may go away)
@@ -152,18 +147,6 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     }
     if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
     r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0; r->warm_mu = 0.0;
-    r->family_kernel = nullptr;
-    {
-        int ms = 0;
-        for (int i = 0; i < d->n_static; ++i) ms += d->m_static[i];
-        const int nfix = d->N_fix > 0 ? d->N_fix : d->N;
-        const char* e = getenv("OBCA_SPECIALISE");
-        if (!(e && atoi(e) == 0) && nfix == d->N && d->n_dyn <= 2) {
-#define OBCA_MATCH_FAMILY_KERNEL(N_, S_, M_) if (d->N == N_ && d->n_static == S_ && ms == M_) r->family_kernel = obca_rollout_fused_kernel_f##N_##_##S_##_##M_;
-            OBCA_FAMILIES(OBCA_MATCH_FAMILY_KERNEL)
-        }
-    }
-    if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS))) rc = OBCA_E_NOMEM;
     r->sched = nullptr; r->n_slots = 1024; r->sched_mode = 2; r->queue_ran = false;
     if (rc == OBCA_OK && !dev_alloc(r, r->sched, (size_t)d->batch + 2 + 16 * 8 + 4 * 4096)) rc = OBCA_E_NOMEM;   // (+ per-workgroup statistics of -DOBCA_RO_STATS builds)
     {
@@ -377,10 +360,7 @@ extern "C" int obca_rollouts_run(obca_rollouts* r, int32_t n_steps, void* hip_st
         if (const char* e = getenv("OBCA_ROLLOUT_LOCAL_STEPS")) { const int v = atoi(e) / OBCA_RO_BLOCK * OBCA_RO_BLOCK; if (v > 0 && v < local_steps) local_steps = v; }
         for (int qmode = queue ? r->sched_mode : 0; ; qmode = 1) {
             const int steps_now = qmode == 2 ? local_steps : (int)n_steps;
-            if (r->family_kernel)
-                hipLaunchKernelGGL(r->family_kernel, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
-                                   (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, steps_now, sched, qmode);
-            else if (r->rows_max <= 256)
+            if (r->rows_max <= 256)
                 hipLaunchKernelGGL(obca_rollout_fused_kernel_r4, dim3(grid), dim3(64), (size_t)r->lds_max, (hipStream_t)hip_stream,
                                    (const rollout::Dev*)r->dD, (const ObcaLaunch*)r->dL, steps_now, sched, qmode);
             else if (r->rows_max <= 320)
