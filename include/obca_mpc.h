@@ -187,11 +187,12 @@ int obca_set_certificate_buffers(obca_handle* h, double* z, double* y);
  * workspace.  Returns OBCA_E_LDS if mode 1 / 3 / 4 cannot hold the shape. */
 int obca_set_mode(obca_handle* h, int mode);
 
-/* Compile-time-shape instantiations.  For the problem shapes the reference's closed-loop driver produces (N = 5 or 6, the three
- * static obstacles of demo1 / demo8 with 1 + 4 + 1 half-space rows, plus 0, 1 or 2 sensed moving rectangles; list: csrc/obca_device.h
- * OBCA_SHAPES) the library holds an instantiation of the one-wavefront kernel with the shape as compile-time constants -- same
- * code, same arithmetic, every output word equal (tests/test_gpu_shapes.py), 10-12 % shorter launches.  obca_solve_batch uses it
- * whenever the handle's shape is one of them and the kernel selection above would run the one-wavefront kernel; on = 0
+/* Compile-time-shape instantiations.  For the problem shapes the reference's closed-loop driver produces with its nine demo
+ * settings (N = 5 or 6; static obstacles plus sensed moving rectangles: (obstacles, rows) = (2, 2) (3, 6) (4, 10) (5, 14) (6, 18))
+ * and for the two halves of the N = 20 benchmark configuration (list: csrc/obca_device.h OBCA_SHAPES, OBCA_MW_SHAPES) the library
+ * holds an instantiation of the kernel with the shape as compile-time constants -- same code, same arithmetic, every output word
+ * equal (tests/test_gpu_shapes.py), 5-15 % shorter launches.  obca_solve_batch uses it whenever the handle's shape is one of them
+ * and the kernel selection above would run the corresponding generic kernel; on = 0
  * (environment at obca_create: OBCA_SPECIALISE=0) forces the generic kernel.  obca_shape_is_specialised: 1 if launches of this
  * handle use an instantiation. */
 int obca_set_shape_specialisation(obca_handle* h, int on);

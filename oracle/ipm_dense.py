@@ -33,10 +33,10 @@ acceptable-point logic with the reference's options for mpc6/mpc8.
 PARITY at the solver boundary: IPOPT cannot run here; the one IPOPT output the
 reference repository holds -- its GIF of the demo9 closed loop, 83 chained solves
 whose Ts_opt the frame titles carry (tests/golden/reference_gif_demo9.json) --
-pins the C twin of this file on 42 consecutive steps with the reference's start
-and on 69 with the window as the first start (tests/test_reference_gif.py; where
-the runs part the solves end in different local optima).  Beyond that run parity is
-UNPINNED.  What else pins this file: (1) the NLP functions are pinned to the
+pins the C twin of this file on 69 consecutive steps with the default start ladder
+(x0 -> window -> zeros; 42 with the reference's literal zero start first:
+tests/test_reference_gif.py; at step 70 the GIF's own answer is the one that is not the
+best optimum).  Beyond that run parity is UNPINNED.  What else pins this file: (1) the NLP functions are pinned to the
 reference's model code (tests/test_oracle_nlp.py); (2) KKT certificates on the
 ORIGINAL NLP and the independent known answers of SURVEY.md Appendix C
 (tests/test_oracle_ipm.py).

@@ -8,8 +8,9 @@
  * NLP: reference src/obca.py:828-1071 (obca_mpc4), :1361-1562 (obca_mpc6), :1564-1758 (obca_mpc8); the
  * function-by-function citations are in oracle/obca_nlp.py, which this file follows line by line and
  * against which it is tested (tests/test_c_oracle.py).  PARITY at the solver boundary: no IPOPT here; pinned on the ONE
- * IPOPT output the reference repository holds (its demo9 GIF: 42 consecutive closed-loop steps show the reference's digits with
- * the reference's start, 69 with the window first -- tests/test_reference_gif.py), UNPINNED beyond that run; the NLP functions
+ * IPOPT output the reference repository holds (its demo9 GIF: 69 consecutive closed-loop steps show the reference's digits with
+ * the default start ladder, 42 with the reference's literal zero start first -- tests/test_reference_gif.py), UNPINNED beyond
+ * that run; the NLP functions
  * are pinned through tests/golden/nlp_eval.json.
  *
  * Build: make -C oracle   ->  oracle/_build/libobca_oracle.so

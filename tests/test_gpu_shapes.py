@@ -10,17 +10,22 @@ from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver impor
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(5, 3, 6), (5, 4, 10), (5, 5, 14), (6, 3, 6), (6, 4, 10), (6, 5, 14)]          # = OBCA_SHAPES
+SHAPES = [(5, 2, 2), (5, 3, 6), (5, 4, 10), (5, 5, 14), (5, 6, 18), (6, 2, 2), (6, 3, 6), (6, 4, 10), (6, 5, 14)]          # = OBCA_SHAPES
 
 
 def _batch(N, nO, B):
-    """C2 generator for the three static obstacles; the gated C3 generator (walls, box, two moving boxes: five obstacles, 14 rows)
-    for the others, its last moving box dropped for four obstacles"""
-    if nO == 3:
-        return sc.make_batch(B, N)
+    """C2 generator for the three static obstacles (its box dropped: the two walls); the gated C3 generator (walls, box, two
+    moving boxes: five obstacles, 14 rows) for the others -- its last moving box dropped for four obstacles, repeated for six"""
+    if nO <= 3:
+        b = sc.make_batch(B, N)
+        if nO == 2:
+            b = dict(b, m=[1, 1], A=np.ascontiguousarray(b["A"][:, :, [0, 5]]), b=np.ascontiguousarray(b["b"][:, :, [0, 5]]))
+        return b
     b = sc.make_batch_c3(B, N, gated=True)
     if nO == 4:
         b = dict(b, m=b["m"][:4], A=np.ascontiguousarray(b["A"][:, :, :10]), b=np.ascontiguousarray(b["b"][:, :, :10]))
+    if nO == 6:
+        b = dict(b, m=list(b["m"]) + [4], A=np.concatenate([b["A"], b["A"][:, :, 10:14]], axis=2), b=np.concatenate([b["b"], b["b"][:, :, 10:14]], axis=2))
     return b
 
 

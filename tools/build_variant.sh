@@ -9,7 +9,7 @@ NAME=$1; shift
 cd "$(dirname "$0")/../vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd/csrc"
 OBJ=/tmp/obca_variant_$NAME
 rm -rf $OBJ; mkdir -p $OBJ
-for f in obca_kernel obca_kernel_mw obca_lpi obca_capi obca_rollout obca_astar obca_kernel_s5_3_6 obca_kernel_s5_4_10 obca_kernel_s5_5_14 obca_kernel_s6_3_6 obca_kernel_s6_4_10 obca_kernel_s6_5_14 obca_kernel_mw_s20_3_6 obca_kernel_mw_s20_5_14; do
+for f in obca_kernel obca_kernel_mw obca_lpi obca_capi obca_rollout obca_astar obca_kernel_s5_2_2 obca_kernel_s5_6_18 obca_kernel_s6_2_2 obca_kernel_s5_3_6 obca_kernel_s5_4_10 obca_kernel_s5_5_14 obca_kernel_s6_3_6 obca_kernel_s6_4_10 obca_kernel_s6_5_14 obca_kernel_mw_s20_3_6 obca_kernel_mw_s20_5_14; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-pass-failed "$@" -c $f.hip -o $OBJ/$f.o &
 done
 wait

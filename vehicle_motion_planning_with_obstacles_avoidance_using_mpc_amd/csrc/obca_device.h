@@ -120,13 +120,15 @@ constexpr ObcaShapeSizes obca_shape_sizes(int N, int nO, int M) {
 }
 /* Compile-time-shape instantiations of the one-wavefront kernel: X(N, nO, M).  With the shape known to the compiler every LDS
    offset is an immediate, the stage loops and the index arithmetic (divisions by nO, M, 4 nO, the stage stride) fold, and the
-   scalar registers that held ~35 array offsets and the layout are free: measured on C2 29.7 -> 26.6 ms per 8192 solves, every
-   output word equal to the generic kernel's (tests/test_gpu_shapes.py).  (The fused closed-loop kernel stays generic: with one
-   inlined body per group it gained 3.5 % on C5 and moved 33 GB of scratch per launch instead of 1 GB -- DESIGN.md section 9.)  Listed: the configurations the reference's closed-loop
-   driver produces -- N_free = N_fix = 5 (the GIF's setting, BASELINE) or 6 (src/closed_loop.py:66-67 as checked in), three
-   static obstacles with 1 + 4 + 1 rows (two walls, one box: demo1 / demo8) plus 0, 1 or 2 sensed moving rectangles of four
-   rows each.  Any other shape runs the generic kernels; OBCA_SPECIALISE=0 / obca_set_shape_specialisation(h, 0) forces them. */
-#define OBCA_SHAPES(X) X(5, 3, 6) X(5, 4, 10) X(5, 5, 14) X(6, 3, 6) X(6, 4, 10) X(6, 5, 14)
+   scalar registers that held ~35 array offsets and the layout are free: measured on C2 29.7 -> 26.5 ms per 8192 solves, every
+   output word equal to the generic kernel's (tests/test_gpu_shapes.py).  Listed: every (obstacles, rows) combination the
+   reference's nine demo settings produce (src/demo_setting.py) -- static obstacles plus the sensed moving rectangles of four rows
+   each: demo1-5 (3, 6) (4, 10); demo6-8 (2, 2) (3, 6) (4, 10); demo9 (5, 14) (6, 18) -- at N_free = N_fix = 5 (the GIF's setting,
+   BASELINE) and 6 (src/closed_loop.py:66-67 as checked in), as far as the one-wavefront kernel holds them (<= 384 rows); plus
+   (5, 14) = three static obstacles and two sensed rectangles (config C5).  Any other shape runs the generic kernels;
+   OBCA_SPECIALISE=0 / obca_set_shape_specialisation(h, 0) forces them.  (The fused closed-loop kernel stays generic: with one
+   inlined body per group it gained 3.5 % on C5 and moved 33 GB of scratch per launch instead of 1 GB -- DESIGN.md section 9.) */
+#define OBCA_SHAPES(X) X(5, 2, 2) X(5, 3, 6) X(5, 4, 10) X(5, 5, 14) X(5, 6, 18) X(6, 2, 2) X(6, 3, 6) X(6, 4, 10) X(6, 5, 14)
 /* ... and of the four-wavefront LDS kernels: the two halves of BASELINE.json's configs[2] (N = 20: free-time against the three
    static obstacles, gated fixed-time against five) */
 #define OBCA_MW_SHAPES(X) X(20, 3, 6) X(20, 5, 14)

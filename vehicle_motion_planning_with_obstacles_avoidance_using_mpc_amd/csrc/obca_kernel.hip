@@ -2494,7 +2494,7 @@ __device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const
 #define OBCA_DEFINE_SHAPE_KERNEL(N_, O_, M_)                                                                                   \
     extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { \
         using SH = ShapeIs<N_, O_, M_>;                                                                                        \
-        solve_with_escalation<SH::RPL, true, false, SH>(A, A2, A3);                                                           \
+        solve_with_escalation<SH::RPL, true, true, SH>(A, A2, A3);                                                            \
     }
 OBCA_TU_SHAPE(OBCA_DEFINE_SHAPE_KERNEL)
 #elif OBCA_NT == 64

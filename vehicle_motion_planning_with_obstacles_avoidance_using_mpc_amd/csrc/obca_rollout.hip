@@ -147,6 +147,7 @@ extern "C" int obca_rollouts_create(const obca_rollout_dims* d, obca_rollouts** 
     }
     if (rc == OBCA_OK && hipEventCreateWithFlags(&r->fork, hipEventDisableTiming) != hipSuccess) rc = OBCA_E_HIP;
     r->dD = nullptr; r->dL = nullptr; r->fused_ok = false; r->lds_max = 0; r->mode = 0; r->warm_mu = 0.0;
+    if (rc == OBCA_OK && !(dev_alloc(r, r->dD, 1) && dev_alloc(r, r->dL, 2 * rollout::MAX_GROUPS))) rc = OBCA_E_NOMEM;
     r->sched = nullptr; r->n_slots = 1024; r->sched_mode = 2; r->queue_ran = false;
     if (rc == OBCA_OK && !dev_alloc(r, r->sched, (size_t)d->batch + 2 + 16 * 8 + 4 * 4096)) rc = OBCA_E_NOMEM;   // (+ per-workgroup statistics of -DOBCA_RO_STATS builds)
     {
