@@ -29,9 +29,9 @@ def _batch(N, nO, B):
     return b
 
 
-def _run(s, b, variant):
+def _run(s, b, variant, **params):
     v = np.full(len(b["variant"]), variant, dtype=np.int32)
-    o = s.solve(v, b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], SolverParams())
+    o = s.solve(v, b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], SolverParams(**params))
     torch.cuda.synchronize()
     return {k: getattr(o, k).cpu().numpy().copy() for k in ("xopt", "uopt", "ts_opt", "status", "iters", "info")}
 
@@ -53,6 +53,23 @@ def test_instantiation_returns_the_generic_kernels_words(shape):
         for k in ref:
             assert np.array_equal(got[k], ref[k], equal_nan=True), (shape, variant, k)
         assert np.isin(ref["status"], (0, 1)).mean() > (0.9 if variant == 4 or nO == 3 else 0.5)
+    s.close()
+
+
+@pytest.mark.parametrize("params", [dict(start_order="window"), dict(start_order="zeros"), dict(single_start=True), dict(max_soc=-1),
+                                    dict(patience=60, retry_iter=40)])
+def test_instantiation_follows_every_option_like_the_generic_kernel(params):
+    """the other starts of the ladder, one start only, no second-order correction, short passes (so that the later starts
+    actually run): same words from the instantiation for (5, 5, 14) and the generic kernel, obca_mpc6 and obca_mpc4"""
+    b = _batch(5, 5, 192)
+    s = BatchSolver(5, b["m"], max_batch=192)
+    for variant in (6, 4):
+        got = _run(s, b, variant, **params)
+        s.set_shape_specialisation(False)
+        ref = _run(s, b, variant, **params)
+        s.set_shape_specialisation(True)
+        for k in ref:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (params, variant, k)
     s.close()
 
 
