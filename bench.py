@@ -206,6 +206,24 @@ def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="
         dt = time.perf_counter() - t
         res["%s_N%d" % (demo, N)] = {"seconds": dt, "feas": bool(cl.feas), "ipm_iters": s.last["iters"], "status": s.last["status"],
                                      "Ts_opt": float(cl.Ts_opt), "reference_published_s": pub.get(N)}
+    # the plan the reference repository shows in images/aStar_vs_openLoopOBCA.png (demo9, N = 50, Q = 0.5 I; fixture
+    # tests/golden/reference_openloop_demo9.json): how far are the picture's dots from this build's poses?
+    try:
+        from tests import reference_openloop
+        s = obca()
+        s.start_order = start_order
+        reference_openloop.plan(s)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        cl = reference_openloop.plan(s)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        d, _ = reference_openloop.marker_distances(reference_openloop.fixture(), cl.xOpt)
+        res["demo9_N50_reference_figure"] = {"seconds": dt, "feas": bool(cl.feas), "ipm_iters": s.last["iters"], "status": s.last["status"],
+                                             "Ts_opt": float(cl.Ts_opt), "markers": int(len(d)), "marker_to_pose_max_m": float(d.max()),
+                                             "marker_to_pose_mean_m": float(d.mean()), "pixel_m": 0.0911}
+    except Exception as e:          # noqa: BLE001
+        res["demo9_N50_reference_figure"] = {"error": repr(e)}
     return res
 
 

@@ -57,9 +57,9 @@ typedef struct obca_params {
        are set (memset / = {0}): every option added later reads 0 as "default". */
     double tol;                        /* [1e-8]  IPOPT tol                                        */
     double rho;                        /* [1e4]   elastic (l1) penalty, unscaled objective units; a free-time solve
-                                                   that ends with elastic variables left is repeated once from the same
-                                                   start with rho x 100 (exact-penalty escalation; the next start begins
-                                                   at rho again)                                            */
+                                                   that ends with elastic variables left is repeated from the same
+                                                   start with rho x 100 and, if they still remain, with rho x 1000
+                                                   (exact-penalty escalation; the next start begins at rho again)  */
     double feas_tol;                   /* [1e-6]  largest elastic variable still called feasible   */
     int32_t max_iter_free;             /* [3000]  IPOPT default, variant 4: bounds EACH pass of a solve (see `patience`) */
     int32_t max_iter_fixed;            /* [1000]  obca.py:1538, variants 6/8: likewise              */

@@ -124,7 +124,7 @@ def split_rows(p):
     return hard, term
 
 
-RHO_ESCALATION = 100.0
+RHO_ESCALATION = (100.0, 1000.0)   # csrc/obca_device.h: OBCA_RHO_ESCALATION -- the penalties tried after the base one, one after the other
 RESTART_MU = 1.0               # barrier parameter the window start begins with (csrc/obca_device.h: OBCA_RESTART_MU)
 WINDOW_SPEED_FRAC = 0.9
 # the three starts of the ladder and the three orders (include/obca_mpc.h: start_order; csrc/obca_device.h: OBCA_START_KIND)
@@ -191,8 +191,9 @@ def solve(p, opts=None, trace=None):
       infeasible.
     * penalty escalation (free-time problem only): the l1 penalty is exact only while rho exceeds the multipliers; if
       obca_mpc4 converges with elastic variables left (what "infeasible" looks like, but also what a too small rho looks
-      like -- seen on the open-loop problem of demo1, N = 10) the SAME start is repeated with rho * 100; the next start
-      begins at the base penalty again (measured on the reference's GIF run: with the raised penalty kept, the window and the
+      like -- seen on the open-loop problem of demo1, N = 10) the SAME start is repeated with rho * 100 and, if elastic
+      variables still remain, with rho * 1000 (the reference's open-loop plan of demo9 at N = 50 needs 1e7: tests/golden/
+      reference_openloop_demo9.json); the next start begins at the base penalty again (measured on the reference's GIF run: with the raised penalty kept, the window and the
       x0 start fail on a problem both solve at the base penalty).
 
     opts: ``start_order`` 0 / 1 / 2 or "x0" / "window" / "zeros"; ``single_start``; ``patience``; ``retry_iter``;
@@ -221,8 +222,9 @@ def solve(p, opts=None, trace=None):
             break
         r_new = run(s, kind, rho0)
         r = r_new if r is None else _accumulate(r_new, r)
-        if r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation"):
-            r = _accumulate(run(s, kind, rho0 * RHO_ESCALATION), r)
+        for mult in RHO_ESCALATION:
+            if r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation"):
+                r = _accumulate(run(s, kind, rho0 * mult), r)
         r.starts_used = s + 1
     r.restarted = r.starts_used > 1
     return r

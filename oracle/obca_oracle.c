@@ -852,7 +852,8 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         o.max_iter_free = prm->max_iter_free > 0 ? prm->max_iter_free : 3000; o.max_iter_fixed = prm->max_iter_fixed > 0 ? prm->max_iter_fixed : 1000;
         o.max_soc = prm->max_soc == 0 ? 4 : (prm->max_soc < 0 ? 0 : prm->max_soc);
         /* the start ladder (oracle/ipm_dense.py:solve): the starts of the order until one ends at a feasible point; obca_mpc4 that
-           converged with elastic variables left repeats the same start once with rho x 100 (the next start begins at the base penalty) */
+           converged with elastic variables left repeats the same start with rho x 100 and, if elastic variables still remain, with rho x 1000
+           (the next start begins at the base penalty) */
         const int order = prm->start_order >= 0 && prm->start_order <= 2 ? prm->start_order : 0;
         const int nstarts = prm->single_start ? 1 : 3;
         const int max_iter_v = p.freeT ? o.max_iter_free : o.max_iter_fixed;
@@ -869,9 +870,9 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
             const double mu0 = kind == KIND_WINDOW ? RESTART_MU : MU_INIT;
             status[q] = solve_one(&p, &o, xo, uo, ts_opt + q, iters + q, io, kind, mu0, cap);
             it_sum += iters[q]; if (io) nf_sum += io[3];
-            if (status[q] == ST_INFEASIBLE && p.variant == 4) {
+            for (int level = 1; level <= 2 && status[q] == ST_INFEASIBLE && p.variant == 4; ++level) {
                 Opts o2 = o;
-                o2.rho = o.rho * 100.0;
+                o2.rho = o.rho * (level == 1 ? 100.0 : 1000.0);         /* csrc/obca_device.h: OBCA_RHO_ESCALATION */
                 status[q] = solve_one(&p, &o2, xo, uo, ts_opt + q, iters + q, io, kind, mu0, cap);
                 it_sum += iters[q]; if (io) nf_sum += io[3];
             }

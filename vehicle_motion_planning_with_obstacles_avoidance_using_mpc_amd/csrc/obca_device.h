@@ -40,7 +40,15 @@
 #define OBCA_ACCEPTABLE_ITER 15
 #define OBCA_KAPPA_SOC 0.99
 #define OBCA_MAX_SOC 4
-#define OBCA_RHO_ESCALATION 100.0   /* obca_mpc4 only: one retry with rho x 100 when elastic variables remain */
+/* obca_mpc4 only: a solve that converged with elastic variables left is repeated from the same start with rho x 100 and, if
+   elastic variables still remain, with rho x 1000 (the l1 penalty is exact only above the multipliers, and "rho too small"
+   looks like "infeasible").  The second level is what the reference's own open-loop plan of demo9 at N = 50 needs (objective
+   8e4: every start ends with elastic variables ~3e-3 up to rho = 1e6 and converges at 1e7 to the plan the reference's figure
+   shows, tests/golden/reference_openloop_demo9.json); beyond it (1e8) the solves crawl. */
+#ifndef OBCA_N_ESCALATIONS
+#define OBCA_N_ESCALATIONS 2
+#endif
+#define OBCA_RHO_ESCALATION(level) ((level) <= 1 ? 100.0 : 1000.0)    /* level 1, 2 */
 /* Start ladder (every variant; rule and measurements in oracle/ipm_dense.py:solve, include/obca_mpc.h: start_order): a solve that
    ended without a feasible point is repeated from the next start of the order.  The three starts:
      OBCA_KIND_X0      all variables 0, Topt = 1, every pose at x0 (IPOPT's first Newton iterate from the reference's start)
@@ -63,9 +71,9 @@
    between.  Later starts: the ones that succeed take 16-117 iterations from the window at N <= 20 (C3 gated, C5). */
 #define OBCA_PATIENCE(N) (500 + 10 * (N))
 #define OBCA_RETRY_ITER(N) (300 + 10 * (N))
-/* One solve = at most three starts x two penalties (obca_mpc4 that converged with elastic variables left at the base penalty:
-   once more from the same start with rho x OBCA_RHO_ESCALATION; the next start begins at the base penalty again). */
-#define OBCA_MAX_PASSES 6
+/* One solve = at most three starts x three penalties (obca_mpc4 that converged with elastic variables left: again from the
+   same start with the next penalty of the escalation; the next start begins at the base penalty again). */
+#define OBCA_MAX_PASSES (3 * (1 + OBCA_N_ESCALATIONS))
 #define OBCA_WINDOW_SPEED_FRAC 0.9
 
 /* Line-search filter capacity: a function of the problem SHAPE only, so that every kernel that can run a shape stops at the

@@ -1641,14 +1641,14 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     //   * feasible point (or nothing to solve): return;
     //   * obca_mpc4 converged with elastic variables left at the base penalty: the l1 penalty is exact only while rho exceeds
     //     the multipliers, so this is what "infeasible" looks like but also what a too small rho looks like (the open-loop
-    //     problem of demo1 at N = 10) -- the SAME start again with rho x 100;
+    //     problems of demo1 at N = 10 and of demo9 at N = 50) -- the SAME start again with rho x 100, then with rho x 1000;
     //   * anything else without a feasible point (infeasible stationary point of the penalty problem, line-search failure,
     //     iteration limit, filter full): the NEXT start of the order, if there is one, at the base penalty again (measured:
     //     keeping the raised penalty makes starts fail that succeed at the base one).
-    // That is at most three starts x two penalties = OBCA_MAX_PASSES solves.  A genuinely infeasible problem stays
+    // That is at most three starts x three penalties = OBCA_MAX_PASSES solves.  A genuinely infeasible problem stays
     // infeasible.  The state of the ladder lives in LDS (it must survive from call to call, and nothing of it may occupy a
     // register during the solve).
-    __shared__ int ladder_state[4];      // [0] current start already repeated with the raised penalty, [1] iterations, [2] factorisations so far, [3] index of the current start
+    __shared__ int ladder_state[4];      // [0] escalation level of the current start (0: base penalty), [1] iterations, [2] factorisations so far, [3] index of the current start
     const int order = Ain.prm.opt.order;
     int start_s = 0, escalated = 0;
     if (!first) {
@@ -1656,10 +1656,10 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 < OBCA_STATUS_NUMERIC) return;
         escalated = __builtin_amdgcn_readfirstlane(ladder_state[0]);
         start_s = __builtin_amdgcn_readfirstlane(ladder_state[3]);
-        if (A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE && !escalated) escalated = 1;
+        if (A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE && escalated < OBCA_N_ESCALATIONS) ++escalated;
         else { escalated = 0; if (++start_s >= Ain.prm.opt.nstarts) return; }
     }
-    const double rho_mult = escalated ? OBCA_RHO_ESCALATION : 1.0;
+    const double rho_mult = escalated ? OBCA_RHO_ESCALATION(escalated) : 1.0;
     const int kind = OBCA_START_KIND(order, start_s);
     const bool from_window = kind == OBCA_KIND_WINDOW;
 
@@ -2445,7 +2445,7 @@ __device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
             if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing (more) to recover
         }
     } else {
-        static_assert(OBCA_MAX_PASSES == 6, "one inlined copy of the body per pass");
+        static_assert(OBCA_MAX_PASSES == 9, "one inlined copy of the body per pass");
         obca_ipm_body<RPL, false, DESC, SHAPE>(A, inst, true);
         if (inst >= A.B) return;
         __syncthreads();                                            // status written by thread 0 of this workgroup
@@ -2462,6 +2462,12 @@ __device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
         obca_ipm_body<RPL, false, DESC, SHAPE>(A3, inst, false);
         __syncthreads();
         obca_ipm_body<RPL, false, DESC, SHAPE>(A2, inst, false);
+        __syncthreads();
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A3, inst, false);
+        __syncthreads();
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A2, inst, false);
+        __syncthreads();
+        obca_ipm_body<RPL, false, DESC, SHAPE>(A3, inst, false);
     }
 }
 // KARG: the descriptors are read through the kernarg segment pointer (constant address space) instead of the by-value

@@ -1452,7 +1452,7 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
     // The start ladder (oracle/ipm_dense.py:solve; csrc/obca_kernel.hip runs the same passes): the starts of the order one after
     // the other until one ends at a feasible point; a free-time solve that converged with elastic variables left is first
-    // repeated from the same start with rho x OBCA_RHO_ESCALATION (the next start begins at the base penalty again).  The caller's
+    // repeated from the same start with rho x 100, then rho x 1000 (OBCA_RHO_ESCALATION; the next start begins at the base penalty again).  The caller's
     // optional warm start takes the place of the first cold start of the order.
     const ObcaOptsDev& O0 = A.prm.opt;
     const int max_iter_v = L.free_T ? O0.max_iter_free : O0.max_iter_fixed;
@@ -1468,10 +1468,10 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
         const double mu0 = use_warm ? A.warm_mu : (kind == OBCA_KIND_WINDOW ? OBCA_RESTART_MU : OBCA_MU_INIT);
         o = solve_instance(L, S, in, O0, z, mu0, kind, cap);
         iters += o.iters; nfact += o.nfact;
-        if (o.status == OBCA_STATUS_INFEASIBLE && L.free_T) {
+        for (int level = 1; level <= OBCA_N_ESCALATIONS && o.status == OBCA_STATUS_INFEASIBLE && L.free_T; ++level) {
             // the l1 penalty is exact only while rho exceeds the multipliers: "rho too small" looks like "infeasible"
             ObcaOptsDev O = O0;
-            O.rho *= OBCA_RHO_ESCALATION;
+            O.rho *= OBCA_RHO_ESCALATION(level);
             o = solve_instance(L, S, in, O, z, mu0, kind, cap);
             iters += o.iters; nfact += o.nfact;
         }
