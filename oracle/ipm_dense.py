@@ -36,7 +36,10 @@ whose Ts_opt the frame titles carry (tests/golden/reference_gif_demo9.json) --
 pins the C twin of this file on 69 consecutive steps with the default start ladder
 (x0 -> window -> zeros; 42 with the reference's literal zero start first:
 tests/test_reference_gif.py; at step 70 the GIF's own answer is the one that is not the
-best optimum).  Beyond that run parity is UNPINNED.  What else pins this file: (1) the NLP functions are pinned to the
+best optimum).  The second output the reference holds -- the picture of its open-loop
+plan of demo9 at N = 50 -- pins the structured core and the kernels, which follow this
+file (tests/test_reference_openloop.py; this dense version is too slow at that size).
+Beyond those two parity is UNPINNED.  What else pins this file: (1) the NLP functions are pinned to the
 reference's model code (tests/test_oracle_nlp.py); (2) KKT certificates on the
 ORIGINAL NLP and the independent known answers of SURVEY.md Appendix C
 (tests/test_oracle_ipm.py).
