@@ -227,6 +227,23 @@ def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="
     return res
 
 
+def report_figures_leg():
+    """closed-loop frames of the reference's project report (tests/golden/reference_report_figures.json: titles = sum(Ts_opt[:k])
+    of runs IPOPT solved) replayed through the product path: how many titles does this build's run show?"""
+    from tests import reference_report
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
+    fx = reference_report.fixture()
+    out = {"fixture": "tests/golden/reference_report_figures.json", "tolerance_s": reference_report.TIME_TOL}
+    for name, setting, n in (("figure12_demo1", reference_report.demo1_setting(), 31), ("figure11_corridor_reconstructed", reference_report.corridor_setting(fx), 64)):
+        t0 = time.perf_counter()
+        cum, _ = reference_report.replay(setting, obca(), n)
+        titles = sorted(f["spend_time"] for f in fx["figure11_corridor" if "11" in name else name]["frames"])
+        hits = reference_report.match(cum, titles)
+        out[name] = {"titles": titles, "nearest_step": [k for k, _ in hits], "distance_s": [round(e, 4) for _, e in hits],
+                     "titles_shown": int(sum(e <= reference_report.TIME_TOL for _, e in hits)), "steps_run": int(len(cum)), "seconds": time.perf_counter() - t0}
+    return out
+
+
 def reference_gif_leg():
     """The one solver output the reference repository holds (its GIF of the demo9 closed loop: sum(Ts_opt[:k]) of 83 chained
     IPOPT solves, fixture tests/golden/reference_gif_demo9.json) replayed through the product path (closedLoop mirror on the
@@ -546,6 +563,7 @@ def main():
                 r["note"] = "obca_params.start_order = OBCA_START_ZEROS_FIRST: the reference's literal all-zero start first (src/obca.py:856) -- the default of rounds 1-3, kept for comparison"
                 return r
             extras = (("reference_gif", reference_gif_leg),
+                      ("reference_report_figures", report_figures_leg),
                       ("window_first", window_first_all),
                       ("zeros_first", zeros_first),
                       ("open_loop", open_loop),
