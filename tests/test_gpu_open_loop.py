@@ -121,8 +121,9 @@ def test_long_horizon_free_time_solves(demo, N):
     st, it = int(out.status[0]), int(out.iters[0])
     print("%s N=%d: ONE instance on the GPU %.3f s (%d iterations, status %d), on one CPU core %.3f s (%d); reference, unspecified hardware: %s"
           % (demo, N, t_gpu, it, st, t_cpu, call["iters"], {10: "3.69 s", 74: "136.7 s"}.get(N, "not published")))
-    # (includes the first launch of the handle: workspace allocation; demo9 at N = 10 runs the whole ladder: ~880 iterations)
-    assert t_gpu < (0.05 if (demo, N) == ("demo1", 10) else 0.12 if N <= 10 else 1.5)
+    # (includes the first launch of the handle: workspace allocation; demo9 at N = 10 runs the whole ladder -- three starts x
+    # three penalties since the escalation has two levels: ~1300 iterations, 0.14 s)
+    assert t_gpu < (0.05 if (demo, N) == ("demo1", 10) else 0.2 if N <= 10 else 1.5)
     if (demo, N) == ("demo9", 10):
         assert st == 2 and not cl.feas       # infeasible by construction, reported as such
         return
