@@ -336,6 +336,8 @@ int obca_rasterise_batch(const double* boxes, int32_t B, int32_t K, double resol
                          uint8_t* grid, void* hip_stream);
 
 const char* obca_strerror(int code);
+/* "obca_mpc 0.3 (gfx950)": 0.2 = the start ladder (start_order / single_start / patience / retry_iter replace restart); 0.3 = second
+ * level of the penalty escalation, compile-time-shape instantiations, obca_rollouts_queue_mode */
 const char* obca_version(void);
 
 #ifdef __cplusplus
