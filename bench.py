@@ -183,16 +183,18 @@ def config_c3(B, N=20, start_order=0):
     return res
 
 
-def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="x0"):
+def open_loop(cases=(("demo9", 10), ("demo9", 74), ("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="x0"):
     """Row N3: the reference's open-loop free-time plan (closedLoop.mpc_openLoop_freeTime, src/closed_loop.py:113-120) as ONE
-    instance through the drop-in `obca` class -- the only timing the reference publishes (src/simulation.py:230-231: N = 74
-    136.69 s, N = 10 3.69 s, hardware unspecified).  Second call timed (the first allocates the handle's workspace)."""
+    instance through the drop-in `obca` class -- the only timing the reference publishes (src/simulation.py:210-231 calc_time,
+    called for demo9 in main.py:28: N = 74 -- the length of demo9's A* route -- 136.69 s, N = 10 3.69 s, hardware unspecified; demo9
+    at N = 10 has no feasible point: its time-scale bound allows too short a path).  Second call timed (the first allocates the
+    handle's workspace)."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.demo_setting import problemSetting
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
-    pub = {10: 3.69, 74: 136.69}
+    pub = {("demo9", 10): 3.69, ("demo9", 74): 136.69}
     res = {"workload": "open-loop free-time plan (obca_mpc4, default start ladder, start/goal-only reference), batch of ONE, host call to host result",
-           "reference_published_s": {"N=10": 3.69, "N=74": 136.69, "source": "src/simulation.py:230-231, hardware unspecified"}}
+           "reference_published_s": {"demo9 N=10": 3.69, "demo9 N=74": 136.69, "source": "src/simulation.py:228-231 (calc_time, main.py:28: demo9), hardware unspecified"}}
     for demo, N in cases:
         s = obca()
         s.start_order = start_order
@@ -205,7 +207,7 @@ def open_loop(cases=(("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         res["%s_N%d" % (demo, N)] = {"seconds": dt, "feas": bool(cl.feas), "ipm_iters": s.last["iters"], "status": s.last["status"],
-                                     "Ts_opt": float(cl.Ts_opt), "reference_published_s": pub.get(N)}
+                                     "Ts_opt": float(cl.Ts_opt), "reference_published_s": pub.get((demo, N))}
     # the plan the reference repository shows in images/aStar_vs_openLoopOBCA.png (demo9, N = 50, Q = 0.5 I; fixture
     # tests/golden/reference_openloop_demo9.json): how far are the picture's dots from this build's poses?
     try:
