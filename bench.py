@@ -362,6 +362,7 @@ def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=Fal
                     "classified": len(same), "feasible_point_exists_solver_failure": int(sum(r["feasible_point_found"] for r in same)),
                     "no_feasible_point_found": int(sum(not r["feasible_point_found"] for r in same)),
                     "host_replay_stops_elsewhere": len(rows) - len(same),
+                    "solver_failures_world_step_variant_status": [list(r["tag"]) for r in same if r["feasible_point_found"]],
                     "method": "host replay of each stopped rollout (structured core), last solve to SciPy SLSQP from three starts on the pinned model, %.1f s" % (time.time() - t1)}
             except Exception as e:          # noqa: BLE001
                 res["stopped_infeasible_split"] = {"error": repr(e)}
