@@ -75,7 +75,7 @@ typedef struct obca_params {
          window  the poses of the reference window xref (first pose x0), inputs by differences clipped to their box
          zeros   the reference's literal start: every variable 0, Topt = 1
        No order makes a problem infeasible that another order solves: all three starts are tried in every order. */
-    int32_t start_order;               /* [OBCA_START_X0_FIRST] one of the OBCA_START_* constants below; anything else:
+    int32_t start_order;               /* [OBCA_START_DEFAULT] one of the OBCA_START_* constants below; anything else:
                                                    OBCA_E_INVAL                                             */
     int32_t single_start;              /* [0]     1 = only the first start of the order (with its penalty escalation) -- what a
                                                    driver asks for where its own fallback follows, as obca_mpc8 follows a
@@ -90,11 +90,16 @@ typedef struct obca_params {
 
 /* obca_params.start_order */
 enum {
-    OBCA_START_X0_FIRST = 0,           /* x0 -> window -> zeros (default)                          */
+    OBCA_START_DEFAULT = 0,            /* obca_mpc4: x0 -> window -> zeros; obca_mpc6 / obca_mpc8: window -> x0 -> zeros.  The free-time
+                                          problem has one optimum on every workload measured and the x0 start needs nothing but x0;
+                                          the fixed-time problems have several, and from the window the solver ends at the lower one far
+                                          more often (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER).  With obca_set_warm_start the stored
+                                          plan stands for x0 and the order is x0's for every variant. */
     OBCA_START_WINDOW_FIRST = 1,       /* window -> x0 -> zeros: fastest where the window is a plausible trajectory
                                           (closed loops along an A* path)                          */
-    OBCA_START_ZEROS_FIRST = 2         /* zeros -> window -> x0: the reference's literal start first (the default of
+    OBCA_START_ZEROS_FIRST = 2,        /* zeros -> window -> x0: the reference's literal start first (the default of
                                           obca_mpc 0.1)                                            */
+    OBCA_START_X0_FIRST = 3            /* x0 -> window -> zeros for every variant (the default of obca_mpc 0.2 / 0.3) */
 };
 
 

@@ -20,7 +20,7 @@ class OracleParams(ctypes.Structure):
                 # as obca_params (include/obca_mpc.h): the start ladder
                 ("start_order", ctypes.c_int), ("single_start", ctypes.c_int), ("patience", ctypes.c_int), ("retry_iter", ctypes.c_int)]
 
-START_ORDERS = {"x0": 0, "window": 1, "zeros": 2}
+START_ORDERS = {"default": 0, "x0": 3, "window": 1, "zeros": 2}
 
 
 _lib = None

@@ -132,8 +132,8 @@ RESTART_MU = 1.0               # barrier parameter the window start begins with 
 WINDOW_SPEED_FRAC = 0.9
 # the three starts of the ladder and the three orders (include/obca_mpc.h: start_order; csrc/obca_device.h: OBCA_START_KIND)
 KIND_X0, KIND_WINDOW, KIND_ZEROS = 0, 1, 2
-START_ORDERS = {0: (KIND_X0, KIND_WINDOW, KIND_ZEROS), 1: (KIND_WINDOW, KIND_X0, KIND_ZEROS), 2: (KIND_ZEROS, KIND_WINDOW, KIND_X0)}
-ORDER_NAMES = {"x0": 0, "window": 1, "zeros": 2}
+START_ORDERS = {1: (KIND_WINDOW, KIND_X0, KIND_ZEROS), 2: (KIND_ZEROS, KIND_WINDOW, KIND_X0), 3: (KIND_X0, KIND_WINDOW, KIND_ZEROS)}
+ORDER_NAMES = {"default": 0, "x0": 3, "window": 1, "zeros": 2}
 
 
 def retry_iter(N):
@@ -199,12 +199,15 @@ def solve(p, opts=None, trace=None):
       reference_openloop_demo9.json); the next start begins at the base penalty again (measured on the reference's GIF run: with the raised penalty kept, the window and the
       x0 start fail on a problem both solve at the base penalty).
 
-    opts: ``start_order`` 0 / 1 / 2 or "x0" / "window" / "zeros"; ``single_start``; ``patience``; ``retry_iter``;
+    opts: ``start_order`` 0 / 1 / 2 / 3 or "default" / "window" / "zeros" / "x0" (include/obca_mpc.h: OBCA_START_*); ``single_start``; ``patience``; ``retry_iter``;
     ``no_escalation``.  With ``single_start`` a pass runs to ``max_iter``; otherwise the first start's passes stop after
     ``patience`` iterations, the later starts' after ``retry_iter``."""
     opts = dict(opts or {})
     order = opts.get("start_order", 0)
-    kinds = START_ORDERS[ORDER_NAMES.get(order, order)]
+    order = ORDER_NAMES.get(order, order)
+    if order == 0:                 # the default: x0 first for the free-time problem, the window first for the fixed-time ones
+        order = 3 if (p.variant == 4 or opts.get("single_start")) else 1          # (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER)
+    kinds = START_ORDERS[order]
     if opts.get("single_start"):
         kinds = kinds[:1]
     max_v = opts.get("max_iter", options_for(p.variant)["max_iter"])

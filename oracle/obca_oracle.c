@@ -364,7 +364,8 @@ typedef struct {
 #define PATIENCE(N) (500 + 10 * (N)) /* csrc/obca_device.h: OBCA_PATIENCE */
 /* the three starts of the ladder and the three orders (include/obca_mpc.h: start_order; csrc/obca_device.h: OBCA_START_KIND) */
 enum { KIND_X0 = 0, KIND_WINDOW = 1, KIND_ZEROS = 2 };
-static const int START_ORDERS[3][3] = {{KIND_X0, KIND_WINDOW, KIND_ZEROS}, {KIND_WINDOW, KIND_X0, KIND_ZEROS}, {KIND_ZEROS, KIND_WINDOW, KIND_X0}};
+/* index: the EFFECTIVE order 1, 2, 3 (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER; 0 = default: 3 for obca_mpc4, 1 for obca_mpc6 / 8) */
+static const int START_ORDERS[4][3] = {{KIND_X0, KIND_WINDOW, KIND_ZEROS}, {KIND_WINDOW, KIND_X0, KIND_ZEROS}, {KIND_ZEROS, KIND_WINDOW, KIND_X0}, {KIND_X0, KIND_WINDOW, KIND_ZEROS}};
 #define KAPPA_MU 0.2
 #define THETA_MU 1.5
 #define KAPPA_EPS 10.0
@@ -854,7 +855,8 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         /* the start ladder (oracle/ipm_dense.py:solve): the starts of the order until one ends at a feasible point; obca_mpc4 that
            converged with elastic variables left repeats the same start with rho x 100 and, if elastic variables still remain, with rho x 1000
            (the next start begins at the base penalty) */
-        const int order = prm->start_order >= 0 && prm->start_order <= 2 ? prm->start_order : 0;
+        const int order0 = prm->start_order >= 0 && prm->start_order <= 3 ? prm->start_order : 0;
+        const int order = order0 != 0 ? order0 : ((p.variant == 4 || prm->single_start) ? 3 : 1);
         const int nstarts = prm->single_start ? 1 : 3;
         const int max_iter_v = p.freeT ? o.max_iter_free : o.max_iter_fixed;
         const int pat = prm->patience > 0 ? prm->patience : PATIENCE(N), ret = prm->retry_iter > 0 ? prm->retry_iter : RETRY_ITER(N);

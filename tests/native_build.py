@@ -74,7 +74,7 @@ class LpiObca:
 
     def __init__(self, engine="lpi"):
         self.calls = []
-        self.start_order = "x0"            # as the drop-in obca class (…_amd/obca.py): "x0" | "window" | "zeros"
+        self.start_order = "default"       # as the drop-in obca class (…_amd/obca.py): "default" | "x0" | "window" | "zeros"
         self.single_start = False
         self.engine = engine               # "lpi": structured core (csrc/obca_lpi_core.h); "oracle": dense C oracle (oracle/obca_oracle.c)
 

@@ -19,13 +19,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # Consecutive steps whose cumulative free time the GIF and this build share, by start order (include/obca_mpc.h: start_order) and
 # engine -- the ONE place these figures live (tests/test_reference_gif.py, tests/test_gpu_reference_gif.py and bench.py read them):
-#   "x0" (default) and "window": 69 steps on every engine; at step 70 IPOPT's own answer is the one that is not the best optimum
+#   "default" (x0 first for obca_mpc4, the window first for obca_mpc6 / 8), "x0" and "window": 69 steps on every engine; at step 70 IPOPT's own answer is the one that is not the best optimum
 #       (its Ts_opt 2.11 s against 1.63 s here, which SLSQP confirms from the window), after which the run follows the GIF's
 #       clock at a constant distance (< 0.5 s) and reaches the goal after 84 steps like the reference's;
 #   "zeros" (the reference's literal all-zero start first): at least 47 steps with the structured core / the kernels and 42 with
 #       the dense C oracle -- from there a cold-started free-time solve settles in another local optimum of the corner turn at
 #       (12, 50), which is why this order is not the default.
-MATCHED = {"x0": {"lpi": 69, "oracle": 69, "gpu": 69}, "window": {"lpi": 69, "oracle": 69, "gpu": 69},
+MATCHED = {"default": {"lpi": 69, "oracle": 69, "gpu": 69}, "x0": {"lpi": 69, "oracle": 69, "gpu": 69}, "window": {"lpi": 69, "oracle": 69, "gpu": 69},
            "zeros": {"lpi": 47, "oracle": 42, "gpu": 47}}
 GIF_STEPS = 83            # solves in the reference's run (its file name carries N = 83; 84 frames)
 # the title is rounded to 0.01 s (half a unit = 0.005) + what `tol = 1e-8` solves of 47 chained steps may differ by

@@ -80,7 +80,7 @@ def test_infeasible_instance_reports_feas_false(nlp_golden, solver_cls):
 @pytest.mark.parametrize("name", ["demo1_dyn_mpc6", "demo1_dyn_mpc8"])
 def test_hard_fixed_time_cases_are_certified(nlp_golden, solver_cls, name):
     """long non-convex runs.  demo1_dyn_mpc6 is SURVEY Appendix C's "mpc6 witness": from the reference's cold start the
-    method ends at an infeasible stationary point (the plan that dives under the moving box), the restart phase finds the
+    method ends at an infeasible stationary point (the plan that dives under the moving box), the window start finds the
     plan that passes above it -- the survey's criterion is feas = True with f <= 0.02974."""
     case = [c for c in nlp_golden if c["name"] == name][0]
     p = build(case)
@@ -90,7 +90,8 @@ def test_hard_fixed_time_cases_are_certified(nlp_golden, solver_cls, name):
     np.testing.assert_allclose(x, r.xopt, rtol=0, atol=1e-5)
     np.testing.assert_allclose(u, r.uopt, rtol=0, atol=1e-5)
     if name == "demo1_dyn_mpc6":
-        assert getattr(r, "restarted", False)
+        assert r.starts_used == 1                                       # the default order starts obca_mpc6 at the window, which finds it
+        assert ipm_dense.solve(p, dict(start_order="x0")).restarted     # (from x0 the method ends under the box first)
         assert r.f <= 0.02974 + 1e-6
     # primal feasibility of the kernel's trajectory in the ORIGINAL NLP (dynamics + bounds on x,u)
     z = p.start_point()

@@ -15,7 +15,7 @@ def _replay(order, n):
     return reference_gif.replay(s, n)
 
 
-@pytest.mark.parametrize("order", ["x0", "window", "zeros"])
+@pytest.mark.parametrize("order", ["default", "x0", "window", "zeros"])
 def test_product_path_shows_the_references_digits(order):
     """default ladder (x0 first) and window first: 69 consecutive steps; the literal zero start first: 47"""
     fx = reference_gif.fixture()
@@ -35,13 +35,13 @@ def test_product_path_shows_the_references_digits(order):
 
 def test_default_run_reaches_the_goal_after_84_steps_like_the_references():
     fx = reference_gif.fixture()
-    cum, xs, cl = _replay("x0", 120)
+    cum, xs, cl = _replay("default", 120)
     assert cl.goal_reached() and cl.k == 84 == fx["setting"]["frames"]
     ref = np.asarray(fx["spend_time"])
     assert np.abs(cum[:reference_gif.GIF_STEPS] - ref[1:]).max() < 0.5
 
 
-@pytest.mark.parametrize("order", ["x0", "window", "zeros"])
+@pytest.mark.parametrize("order", ["default", "x0", "window", "zeros"])
 def test_gpu_replay_is_the_host_cores_replay(order):
     """same closed loop on the CPU build of the structured core: the chained steps agree to solver tolerance"""
     n = reference_gif.MATCHED[order]["gpu"]

@@ -53,7 +53,7 @@ def test_out_of_range_start_fields_are_rejected():
     b = sc.make_batch(4, 5)
     s = BatchSolver(5, b["m"], max_batch=4)
     args = (b["variant"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"])
-    for bad in (dict(start_order=3), dict(start_order=-1), dict(single_start=2)):
+    for bad in (dict(start_order=4), dict(start_order=-1), dict(single_start=2)):
         prm = SolverParams().to_c()
         for k, v in bad.items():
             setattr(prm, k, v)

@@ -39,7 +39,7 @@ def _check(fx, engine, order, n):
 
 
 @pytest.mark.parametrize("engine", ["lpi", "oracle"])
-@pytest.mark.parametrize("order", ["x0", "window"])
+@pytest.mark.parametrize("order", ["default", "x0", "window"])
 def test_cpu_solvers_replay_69_steps_of_the_reference_run(fx, engine, order):
     """The default start ladder (x0 -> window -> zeros) and the window-first order: engine "oracle" is the dense C oracle
     (oracle/obca_oracle.c) -- this is what pins the ORACLE to the reference; engine "lpi" the structured core the kernels are

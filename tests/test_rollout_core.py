@@ -17,7 +17,7 @@ from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios im
 TOL = 1e-9          # fp64; libm vs numpy cos/sin/atan2 may differ in the last bit, the solves amplify that slightly
 
 
-def host_rollout(setting, N, n_steps, start_order="x0"):
+def host_rollout(setting, N, n_steps, start_order="default"):
     solver = native_build.LpiObca()
     solver.start_order = start_order
     cl = closedLoop(setting, solver=solver)
@@ -30,7 +30,7 @@ def host_rollout(setting, N, n_steps, start_order="x0"):
     return cl, solver
 
 
-def compare(settings, N, n_steps, start_order="x0"):
+def compare(settings, N, n_steps, start_order="default"):
     w = pack_worlds(copy.deepcopy(settings))
     out = native_build.rollout_run(w, N, c_oracle.default_params(start_order=start_order), n_steps)
     for i, st in enumerate(settings):

@@ -25,13 +25,13 @@ def _packed(case, **extra):
     return (case["variant"], a["N"], m, x0[None], u0[None], xr[None], A[None], b[None], [ts], term[None], c_oracle.default_params(**kw))
 
 
-@pytest.mark.parametrize("order", ["x0", "window", "zeros"])
+@pytest.mark.parametrize("order", ["default", "x0", "window", "zeros"])
 def test_mpc6_witness_is_met_by_all_three_cpu_implementations_in_every_order(nlp_golden, order):
     case = [c for c in nlp_golden if c["name"] == "demo1_dyn_mpc6"][0]
     p = build(case)
     r = ipm_dense.solve(p, dict(start_order=order))
     assert r.feas and r.f <= F_WITNESS + 1e-6
-    assert r.restarted == (order != "window")                      # x0 and zeros end under the box; the window start finds the plan
+    assert r.restarted == (order not in ("window", "default"))       # x0 and zeros end under the box; the window start (the default for obca_mpc6) finds the plan
     cert = ipm_dense.kkt_certificate(p, r)
     assert cert["primal"] < 1e-8 and cert["stationarity"] < 1e-6 and cert["complementarity"] < 1e-6
     assert r.xopt[1].max() > 7.9                                   # passes ABOVE the moving box (the witness's class)
@@ -56,7 +56,7 @@ def test_single_start_ends_where_the_first_start_ends(nlp_golden, order):
     assert native_build.lpi_solve(*args)["status"][0] == 2
 
 
-@pytest.mark.parametrize("order", ["x0", "window", "zeros"])
+@pytest.mark.parametrize("order", ["default", "x0", "window", "zeros"])
 def test_a_genuinely_infeasible_problem_stays_infeasible(nlp_golden, order):
     """demo1 at N = 5 (the terminal pose collides): all three starts run, each with its penalty escalation,
     feas stays False -- and the whole sequence is the same in the three implementations, iterate for iterate"""
@@ -78,14 +78,15 @@ def test_iteration_limits_of_the_ladder(nlp_golden):
     infeasible stationary point, the window start 49 to the plan."""
     case = [c for c in nlp_golden if c["name"] == "demo1_dyn_mpc6"][0]
     for engine in (c_oracle.solve_batch, native_build.lpi_solve):
-        it0 = engine(*_packed(case, single_start=1))["iters"][0]               # the x0 start alone, to its end
-        o = engine(*_packed(case, patience=20))                                  # first start abandoned after 20 iterations
+        x0f = dict(start_order="x0")                                             # (x0 first: the default order starts obca_mpc6 at the window)
+        it0 = engine(*_packed(case, single_start=1, **x0f))["iters"][0]        # the x0 start alone, to its end
+        o = engine(*_packed(case, patience=20, **x0f))                           # first start abandoned after 20 iterations
         assert o["status"][0] == 0 and 20 < o["iters"][0] < it0 + 49
-        o = engine(*_packed(case, patience=20, retry_iter=10))                   # ... and the later starts after 10 each
+        o = engine(*_packed(case, patience=20, retry_iter=10, **x0f))            # ... and the later starts after 10 each
         assert o["status"][0] == -1 and o["iters"][0] <= 20 + 10 + 10 + 3
-        o = engine(*_packed(case, single_start=1, patience=20, max_iter_fixed=2000))
+        o = engine(*_packed(case, single_start=1, patience=20, max_iter_fixed=2000, **x0f))
         assert o["status"][0] == 2 and o["iters"][0] == it0                      # single start: patience does not apply
-        o = engine(*_packed(case, single_start=1, max_iter_fixed=30))
+        o = engine(*_packed(case, single_start=1, max_iter_fixed=30, **x0f))
         assert o["status"][0] == -1 and o["iters"][0] <= 31                      # ... max_iter does
 
 
@@ -148,8 +149,8 @@ def test_c3_gated_batch_with_the_ladder_structured_core_against_dense_oracle():
     N, B = 8, 32
     b = sc.make_batch_c3(B, N, gated=True)
     args = (b["variant"], N, b["m"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"])
-    cold = native_build.lpi_solve(*args, params=c_oracle.default_params(single_start=1))
-    got = native_build.lpi_solve(*args, cert=True)
+    cold = native_build.lpi_solve(*args, params=c_oracle.default_params(single_start=1, start_order="x0"))     # the x0 start alone
+    got = native_build.lpi_solve(*args, cert=True)                     # default: the window first for obca_mpc6, then x0, then zeros
     ref = c_oracle.solve_batch(*args, threads=8)
     ok_cold, ok = np.isin(cold["status"], (0, 1)), np.isin(got["status"], (0, 1))
     assert (ok | ~ok_cold).all()                                   # nothing that converged cold is lost

@@ -4,10 +4,15 @@ import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-dr = DeviceRollouts(pack_worlds([sc.make_world_c5(i, n_dyn=2) for i in range(B)]), N=5)
+order = sys.argv[2] if len(sys.argv) > 2 else "x0"
+w = pack_worlds([sc.make_world_c5(i, n_dyn=2) for i in range(B)])
+dr = DeviceRollouts(w, N=5, params=SolverParams(xU=(39.0, 10.0), start_order=order))
+print("start order", order, "-- stopped rollouts:", end=" ")
 dr.run(); o = {k: v.cpu().numpy() for k, v in dr.read().items()}
 v, it, st = o["variant"], o["iters"], o["status"]
+print(int((o["flags"] == 3).sum()), "converged steps", int(o["steps"].sum()))
 tot = it[v > 0].sum()
 for var in (4, 6, 8):
     m = v == var

@@ -18,7 +18,7 @@ out = None
 ts = []
 for i in range(4):
     torch.cuda.synchronize(); t = time.time()
-    out = s.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], SolverParams(), out=out)
+    out = s.solve(dv["variant"], dv["x0"], dv["u0"], dv["xref"], dv["A"], dv["b"], dv["Ts"], dv["term"], SolverParams(start_order=os.environ.get("OBCA_ORDER", "default")), out=out)
     torch.cuda.synchronize(); ts.append(time.time() - t)
 st = out.status.cpu().numpy()
 print("%s %s B=%d: %.2f ms -> %.0f solves/s ok %.4f iters %.2f  status counts %s" % (os.environ.get("OBCA_LIB", "default"), what, B, min(ts) * 1e3, B / min(ts),

@@ -35,8 +35,8 @@ class ObcaParams(ctypes.Structure):
 
 
 # obca_params.start_order (include/obca_mpc.h)
-START_X0_FIRST, START_WINDOW_FIRST, START_ZEROS_FIRST = 0, 1, 2
-START_ORDERS = {"x0": START_X0_FIRST, "window": START_WINDOW_FIRST, "zeros": START_ZEROS_FIRST}
+START_DEFAULT, START_WINDOW_FIRST, START_ZEROS_FIRST, START_X0_FIRST = 0, 1, 2, 3
+START_ORDERS = {"default": START_DEFAULT, "x0": START_X0_FIRST, "window": START_WINDOW_FIRST, "zeros": START_ZEROS_FIRST}
 
 
 class ObcaRolloutDims(ctypes.Structure):

@@ -54,16 +54,29 @@
      OBCA_KIND_X0      all variables 0, Topt = 1, every pose at x0 (IPOPT's first Newton iterate from the reference's start)
      OBCA_KIND_WINDOW  poses = xref (first pose x0), inputs by differences clipped to their box, free-time problem: the time
                        scale at which the window is driven at OBCA_WINDOW_SPEED_FRAC of the speed bound -- with a larger initial
-                       barrier parameter (IPOPT's restoration phase likewise raises mu to max(mu, ||c||_inf))
+                       barrier parameter (OBCA_RESTART_MU)
      OBCA_KIND_ZEROS   the reference's literal start (src/obca.py:856): all variables 0, Topt = 1 */
 #define OBCA_KIND_X0 0
 #define OBCA_KIND_WINDOW 1
 #define OBCA_KIND_ZEROS 2
-/* kind of start s = 0, 1, 2 of obca_params.start_order o (two bits per start): x0/window/zeros, window/x0/zeros, zeros/window/x0 */
+/* obca_params.start_order = OBCA_START_DEFAULT (0) means: x0 first for the free-time problem (obca_mpc4: one optimum on the bench
+   workloads, and the x0 start needs nothing but x0), the reference window first for the fixed-time ones (obca_mpc6 / obca_mpc8: several
+   local optima -- measured on 2048 gated instances at N = 20 the window start ends lower than x0 on 73-76 % of those both solve and
+   solves 95 % alone against 80 %, profiles/r04_start_quality.txt).  A caller's warm start stands for x0, so it keeps x0's order. */
+#ifndef OBCA_DEFAULT_ORDER_MPC8
+#define OBCA_DEFAULT_ORDER_MPC8 1
+#endif
+#define OBCA_EFFECTIVE_ORDER(o, variant, warm, single) ((o) != 0 ? (o) : (((variant) == 4 || (warm) || (single)) ? 3 : (variant) == 8 ? OBCA_DEFAULT_ORDER_MPC8 : 1))
+/* kind of start s = 0, 1, 2 of the EFFECTIVE order o = 1, 2, 3 (two bits per start): window/x0/zeros, zeros/window/x0, x0/window/zeros */
 #define OBCA_START_KIND(o, s) (((((o) == 1) ? 0x21 : ((o) == 2) ? 0x06 : 0x24) >> (2 * (s))) & 3)
 /* the caller's optional warm start (obca_set_warm_start) takes the place of the first COLD start of the order */
 #define OBCA_WARM_KIND(o) ((o) == 2 ? OBCA_KIND_ZEROS : OBCA_KIND_X0)
+/* barrier parameter the window start begins with (IPOPT's restoration phase likewise raises mu to max(mu, ||c||_inf)).  Measured
+   in round 4 with 0.1 instead: the gated N = 20 launch 128 instead of 194 ms per 2048 and the same reference-held digits, but the
+   window start then no longer finds the plan of SURVEY Appendix C's obca_mpc6 witness (demo1_dyn_mpc6 ends feas = False): kept. */
+#ifndef OBCA_RESTART_MU
 #define OBCA_RESTART_MU 1.0
+#endif
 /* Iteration limits of the passes while further starts remain (obca_params.patience / retry_iter; <= 0 selects these):
    the first start's passes are abandoned for the next start after OBCA_PATIENCE iterations.  Measured (round 3, git history of tools/restart_study.py;
    DESIGN.md): solves either converge well below it -- N = 5: <= 301 iterations, N = 20: <= 389, N = 74: ~500 per pass -- or
@@ -146,7 +159,7 @@ struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
 struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, order, nstarts, patience, retry_iter, pad_; };
 /* the four start fields of obca_params -> their resolved form; false: start_order / single_start outside its range */
 static inline bool obca_resolve_starts(ObcaOptsDev* o, int start_order, int single_start, int patience, int retry_iter, int N) {
-    if (start_order < OBCA_START_X0_FIRST || start_order > OBCA_START_ZEROS_FIRST || single_start < 0 || single_start > 1) return false;
+    if (start_order < OBCA_START_DEFAULT || start_order > OBCA_START_X0_FIRST || single_start < 0 || single_start > 1) return false;
     o->order = start_order;
     o->nstarts = single_start ? 1 : 3;
     o->patience = patience > 0 ? patience : OBCA_PATIENCE(N);

@@ -1649,7 +1649,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     // infeasible.  The state of the ladder lives in LDS (it must survive from call to call, and nothing of it may occupy a
     // register during the solve).
     __shared__ int ladder_state[4];      // [0] escalation level of the current start (0: base penalty), [1] iterations, [2] factorisations so far, [3] index of the current start
-    const int order = Ain.prm.opt.order;
+    const int order = OBCA_EFFECTIVE_ORDER(Ain.prm.opt.order, A.variant[inst], A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0), Ain.prm.opt.nstarts == 1);
     int start_s = 0, escalated = 0;
     if (!first) {
         const int st0 = __builtin_amdgcn_readfirstlane(A.status[inst]);     // wave-uniform: the flags below stay scalar

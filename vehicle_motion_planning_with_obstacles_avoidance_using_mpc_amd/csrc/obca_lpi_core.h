@@ -1461,9 +1461,10 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     int iters = 0, nfact = 0;
     for (int s = 0; s < O0.nstarts; ++s) {
         if (s > 0 && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) break;
-        const int kind = OBCA_START_KIND(O0.order, s);
+        const int order = OBCA_EFFECTIVE_ORDER(O0.order, L.variant, warm, O0.nstarts == 1);
+        const int kind = OBCA_START_KIND(order, s);
         const int cap = O0.nstarts == 1 ? max_iter_v : (s == 0 ? O0.patience : O0.retry_iter);
-        const bool use_warm = warm && kind == OBCA_WARM_KIND(O0.order);
+        const bool use_warm = warm && kind == OBCA_WARM_KIND(order);
         const double* z = use_warm ? A.warm_z + inst * (size_t)A.n_max : nullptr;
         const double mu0 = use_warm ? A.warm_mu : (kind == OBCA_KIND_WINDOW ? OBCA_RESTART_MU : OBCA_MU_INIT);
         o = solve_instance(L, S, in, O0, z, mu0, kind, cap);
