@@ -183,7 +183,7 @@ def config_c3(B, N=20, start_order=0):
     return res
 
 
-def open_loop(cases=(("demo9", 10), ("demo9", 74), ("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="x0"):
+def open_loop(cases=(("demo9", 10), ("demo9", 74), ("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="default"):
     """Row N3: the reference's open-loop free-time plan (closedLoop.mpc_openLoop_freeTime, src/closed_loop.py:113-120) as ONE
     instance through the drop-in `obca` class -- the only timing the reference publishes (src/simulation.py:210-231 calc_time,
     called for demo9 in main.py:28: N = 74 -- the length of demo9's A* route -- 136.69 s, N = 10 3.69 s, hardware unspecified; demo9
@@ -254,7 +254,7 @@ def reference_gif_leg():
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
     ref = np.asarray(reference_gif.fixture()["spend_time"][1:])
     out = {"fixture": "tests/golden/reference_gif_demo9.json (83 steps, titles rounded to 0.01 s)", "tolerance_s": reference_gif.TIME_TOL}
-    for name in ("x0", "window", "zeros"):          # include/obca_mpc.h: start_order; "x0" is the default
+    for name in ("default", "x0", "window", "zeros"):          # include/obca_mpc.h: start_order
         s = obca()
         s.start_order = name
         iters = []

@@ -17,8 +17,9 @@ def main():
     ap.add_argument("demo", nargs="?", default="demo8")
     ap.add_argument("--monte-carlo", type=int, default=0, help="number of seeded C5 worlds instead of one demo")
     ap.add_argument("--warm-start", action="store_true", help="optional extension, not reference behaviour")
-    ap.add_argument("--start-order", choices=("x0", "window", "zeros"), default="x0",
-                    help="obca_params.start_order (include/obca_mpc.h): x0 -> window -> zeros (default), the reference window first, or the reference's literal all-zero start first")
+    ap.add_argument("--start-order", choices=("default", "x0", "window", "zeros"), default="default",
+                    help="obca_params.start_order (include/obca_mpc.h): default = x0 first for obca_mpc4, the reference window first for obca_mpc6 / 8; "
+                         "or that start first for every variant (zeros = the reference's literal all-zero start)")
     args = ap.parse_args()
     import __graft_entry__ as ge
     ge.build()
@@ -38,7 +39,7 @@ def main():
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
     w = pack_worlds([make_world_c5(i) for i in range(args.monte_carlo)])
     prm = None
-    if args.start_order != "x0":
+    if args.start_order != "default":
         from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
         prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), start_order=args.start_order)
     dr = DeviceRollouts(w, N=5, warm_start=0.1 if args.warm_start else None, params=prm)

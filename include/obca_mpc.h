@@ -93,8 +93,10 @@ enum {
     OBCA_START_DEFAULT = 0,            /* obca_mpc4: x0 -> window -> zeros; obca_mpc6 / obca_mpc8: window -> x0 -> zeros.  The free-time
                                           problem has one optimum on every workload measured and the x0 start needs nothing but x0;
                                           the fixed-time problems have several, and from the window the solver ends at the lower one far
-                                          more often (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER).  With obca_set_warm_start the stored
-                                          plan stands for x0 and the order is x0's for every variant. */
+                                          more often (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER).  Two exceptions keep x0 first for every
+                                          variant: single_start = 1 (a caller with its own fallback wants the start that fails fastest:
+                                          the closed loop's obca_mpc6 before obca_mpc8) and obca_set_warm_start (the stored plan stands
+                                          for x0). */
     OBCA_START_WINDOW_FIRST = 1,       /* window -> x0 -> zeros: fastest where the window is a plausible trajectory
                                           (closed loops along an A* path)                          */
     OBCA_START_ZEROS_FIRST = 2,        /* zeros -> window -> x0: the reference's literal start first (the default of
@@ -341,8 +343,9 @@ int obca_rasterise_batch(const double* boxes, int32_t B, int32_t K, double resol
                          uint8_t* grid, void* hip_stream);
 
 const char* obca_strerror(int code);
-/* "obca_mpc 0.3 (gfx950)": 0.2 = the start ladder (start_order / single_start / patience / retry_iter replace restart); 0.3 = second
- * level of the penalty escalation, compile-time-shape instantiations, obca_rollouts_queue_mode */
+/* "obca_mpc 0.4 (gfx950)": 0.2 = the start ladder (start_order / single_start / patience / retry_iter replace restart); 0.3 = second
+ * level of the penalty escalation, compile-time-shape instantiations, obca_rollouts_queue_mode; 0.4 = OBCA_START_DEFAULT per variant
+ * (OBCA_START_X0_FIRST moved from 0 to 3) */
 const char* obca_version(void);
 
 #ifdef __cplusplus

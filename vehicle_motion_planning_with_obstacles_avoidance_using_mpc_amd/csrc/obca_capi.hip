@@ -394,4 +394,4 @@ extern "C" const char* obca_strerror(int code) {
     }
 }
 
-extern "C" const char* obca_version(void) { return "obca_mpc 0.3 (gfx950)"; }
+extern "C" const char* obca_version(void) { return "obca_mpc 0.4 (gfx950)"; }

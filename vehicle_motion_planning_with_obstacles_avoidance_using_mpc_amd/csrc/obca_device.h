@@ -62,7 +62,9 @@
 /* obca_params.start_order = OBCA_START_DEFAULT (0) means: x0 first for the free-time problem (obca_mpc4: one optimum on the bench
    workloads, and the x0 start needs nothing but x0), the reference window first for the fixed-time ones (obca_mpc6 / obca_mpc8: several
    local optima -- measured on 2048 gated instances at N = 20 the window start ends lower than x0 on 73-76 % of those both solve and
-   solves 95 % alone against 80 %, profiles/r04_start_quality.txt).  A caller's warm start stands for x0, so it keeps x0's order. */
+   solves 95 % alone against 80 %, profiles/r04_start_quality.txt).  A caller's warm start stands for x0, so it keeps x0's order; so does
+   a single-start call -- its caller has a fallback of its own and is served best by the start that fails fastest (C5, where the
+   terminal set makes obca_mpc6 fail on half of the gated steps: 0.546 s with x0 there, 0.648 s with the window). */
 #ifndef OBCA_DEFAULT_ORDER_MPC8
 #define OBCA_DEFAULT_ORDER_MPC8 1
 #endif
