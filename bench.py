@@ -369,6 +369,26 @@ def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=Fal
     return res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside any launcher: re-run this command as N ranks, one per GPU of this node, under
+    torch.distributed.run (rendezvous on 127.0.0.1, a free port) -- the same command line the driver would write by hand.
+    Fails loudly (non-zero, no JSON line) when the node has fewer than N GPUs: a line that says n_gpus 1 must never come
+    out of a --gpus N call."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node -- not running (no line printed)\n" % (n, have))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,7 +405,12 @@ def main():
                     help="config C5 reported beside the headline number at N=1 (0 = skip)")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))            # a bare `bench.py --gpus N` starts its own N ranks (one per GPU, RCCL)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks -- the line's n_gpus is the number of ranks, "
+                 "so the two must agree" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
