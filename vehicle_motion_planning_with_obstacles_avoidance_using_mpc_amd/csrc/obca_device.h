@@ -59,6 +59,19 @@
 #define OBCA_KIND_X0 0
 #define OBCA_KIND_WINDOW 1
 #define OBCA_KIND_ZEROS 2
+/* The dodge rung (fixed-time problems, after every start of the order ended without a feasible point; include/obca_mpc.h: dodge).
+   Where the reference window runs head-on into an obstacle the l1 penalty problem has a stationary point that is symmetric about
+   the window -- the plan brakes in front of the obstacle, the terminal set and the distance rows share the violation -- and all
+   three starts of the order end there although a plan around the obstacle exists (first seen on the reference's demo11 run,
+   steps 21-25: tests/test_reference_demo11.py).  Two more passes start from the window moved sideways by OBCA_DODGE_OFFSET metres
+   (ramped in over the first OBCA_DODGE_RAMP stages; headings along the moved poses, inputs by differences), to the right
+   (OBCA_KIND_DODGE_R) and to the left (OBCA_KIND_DODGE_L) of the direction of travel, with lambda / mu of every (stage, obstacle)
+   pair set to the separating half-space of the largest gap (lambda = e_j / ||A_j||, mu from the rotation equalities).  Both run;
+   the answer is the feasible one with the lower objective. */
+#define OBCA_KIND_DODGE_R 3
+#define OBCA_KIND_DODGE_L 4
+#define OBCA_DODGE_OFFSET 3.0
+#define OBCA_DODGE_RAMP 3
 /* obca_params.start_order = OBCA_START_DEFAULT (0) means: x0 first for the free-time problem (obca_mpc4: one optimum on the bench
    workloads, and the x0 start needs nothing but x0), the reference window first for the fixed-time ones (obca_mpc6 / obca_mpc8: several
    local optima -- measured on 2048 gated instances at N = 20 the window start ends lower than x0 on 73-76 % of those both solve and
@@ -158,7 +171,7 @@ constexpr ObcaShapeSizes obca_shape_sizes(int N, int nO, int M) {
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
 /* order: obca_params.start_order (validated); nstarts: 1 (single_start) or 3; patience / retry_iter: resolved (> 0) */
-struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, order, nstarts, patience, retry_iter, pad_; };
+struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, order, nstarts, patience, retry_iter, dodge; };
 /* the four start fields of obca_params -> their resolved form; false: start_order / single_start outside its range */
 static inline bool obca_resolve_starts(ObcaOptsDev* o, int start_order, int single_start, int patience, int retry_iter, int N) {
     if (start_order < OBCA_START_DEFAULT || start_order > OBCA_START_X0_FIRST || single_start < 0 || single_start > 1) return false;
@@ -166,7 +179,7 @@ static inline bool obca_resolve_starts(ObcaOptsDev* o, int start_order, int sing
     o->nstarts = single_start ? 1 : 3;
     o->patience = patience > 0 ? patience : OBCA_PATIENCE(N);
     o->retry_iter = retry_iter > 0 ? retry_iter : OBCA_RETRY_ITER(N);
-    o->pad_ = 0;
+    o->dodge = 0;
     return true;
 }
 struct ObcaParamsDev {

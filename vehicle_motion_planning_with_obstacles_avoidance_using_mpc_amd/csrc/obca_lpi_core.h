@@ -991,6 +991,79 @@ LPI_FN double row_barrier_lpi(double lo, double up, bool eq, double s, double p,
 // ---------------------------------------------------------------- one instance, start to finish
 struct Out { int status, iters, nfact; double f, elastic, E0, ts_opt, sf; };
 
+// The dodge starts (csrc/obca_device.h: OBCA_KIND_DODGE_R / _L; oracle/ipm_dense.py:dodge_start): the window moved sideways by
+// side * OBCA_DODGE_OFFSET (side = -1: to the right of the direction of travel, +1: to the left), ramped in over the first
+// OBCA_DODGE_RAMP stages; headings along the moved poses (continued from x0's, no jump by 2 pi), inputs by differences clipped to
+// their box, the free-time scale as the window start's; lambda, mu of every (stage, obstacle) pair: the half-space row with the
+// largest gap to the car at that pose, lambda = 1 / ||A_j|| on it, mu from the rotation equalities G'mu = -R A'lambda.
+LPI_FN void dodge_start(const Lay& L, const Sh& S, const Inst& in, double side) {
+    const int N1 = L.N + 1;
+    for (int k = 0; k <= L.N; ++k) {
+        double px = (k == 0) ? in.x0[0] : S.xref[0 * N1 + k], py = (k == 0) ? in.x0[1] : S.xref[1 * N1 + k];
+        if (k > 0) {
+            const int ka = k - 1, kb = k + 1 <= L.N ? k + 1 : L.N;
+            const double ax = S.xref[0 * N1 + kb] - ((ka == 0) ? in.x0[0] : S.xref[0 * N1 + ka]);
+            const double ay = S.xref[1 * N1 + kb] - ((ka == 0) ? in.x0[1] : S.xref[1 * N1 + ka]);
+            const double len = sqrt(ax * ax + ay * ay);
+            const double th = S.xref[2 * N1 + k];
+            const double nx = len > 1e-9 ? -ay / len : -sin(th), ny = len > 1e-9 ? ax / len : cos(th);
+            const double w = side * OBCA_DODGE_OFFSET * (k < OBCA_DODGE_RAMP ? (double)k / OBCA_DODGE_RAMP : 1.0);
+            px += w * nx; py += w * ny;
+        }
+        S.x[L.ip(k)] = px; S.x[L.ip(k) + 1] = py;
+    }
+    S.x[L.ip(0) + 2] = in.x0[2];
+    for (int k = 1; k <= L.N; ++k) {
+        const double prev = S.x[L.ip(k - 1) + 2];
+        double th = prev;
+        if (k < L.N) {
+            const double ddx = S.x[L.ip(k + 1)] - S.x[L.ip(k)], ddy = S.x[L.ip(k + 1) + 1] - S.x[L.ip(k) + 1];
+            if (ddx * ddx + ddy * ddy > 1e-18) {
+                double d = atan2(ddy, ddx) - prev;
+                d -= 6.283185307179586 * floor(d / 6.283185307179586 + 0.5);      // nearest representative to the previous heading
+                th = prev + d;
+            }
+        }
+        S.x[L.ip(k) + 2] = th;
+    }
+    if (L.free_T) {
+        double len = 0.0;
+        for (int k = 0; k < L.N; ++k) {
+            const double ddx = S.x[L.ip(k + 1)] - S.x[L.ip(k)], ddy = S.x[L.ip(k + 1) + 1] - S.x[L.ip(k) + 1];
+            len += sqrt(ddx * ddx + ddy * ddy);
+        }
+        S.x[L.iT()] = fmin(fmax(1.0, len / (L.N * OBCA_WINDOW_SPEED_FRAC * in.uU[0] * in.Ts)), fmax(1.0, in.Tmax));
+    }
+    const double h = in.Ts * (L.free_T ? S.x[L.iT()] : 1.0);
+    for (int k = 0; k < L.N; ++k) {
+        const double ddx = S.x[L.ip(k + 1)] - S.x[L.ip(k)], ddy = S.x[L.ip(k + 1) + 1] - S.x[L.ip(k) + 1];
+        const double dth = S.x[L.ip(k + 1) + 2] - S.x[L.ip(k) + 2];
+        S.x[L.iu(k)] = fmin(fmax(sqrt(ddx * ddx + ddy * ddy) / h, in.uL[0]), in.uU[0]);
+        S.x[L.iu(k) + 1] = fmin(fmax(dth / h, in.uL[1]), in.uU[1]);
+    }
+    for (int k = 0; k <= L.N; ++k) {
+        const double th = S.x[L.ip(k) + 2], ct = cos(th), st = sin(th);
+        const double tx = S.x[L.ip(k)] + ct * in.off, ty = S.x[L.ip(k) + 1] + st * in.off;
+        for (int i = 0; i < L.nO; ++i) {
+            const int o0 = S.offm[i], o1 = S.offm[i + 1];
+            int jb = o0;
+            double gb = -INFINITY, mub[4] = {0.0, 0.0, 0.0, 0.0}, lb = 0.0;
+            for (int j = o0; j < o1; ++j) {
+                const double a0 = S.Aobs[(k * L.M + j) * 2], a1 = S.Aobs[(k * L.M + j) * 2 + 1];
+                const double nrm = sqrt(a0 * a0 + a1 * a1);
+                if (!(nrm > 0.0)) continue;
+                const double v0 = a0 / nrm, v1 = a1 / nrm;
+                const double r0 = ct * v0 + st * v1, r1 = -st * v0 + ct * v1;
+                const double m0 = fmax(-r0, 0.0), m1 = fmax(-r1, 0.0), m2 = fmax(r0, 0.0), m3 = fmax(r1, 0.0);
+                const double gap = -(in.gego[0] * m0 + in.gego[1] * m1 + in.gego[2] * m2 + in.gego[3] * m3) + (a0 * tx + a1 * ty - S.bobs[k * L.M + j]) / nrm;
+                if (gap > gb) { gb = gap; jb = j; lb = 1.0 / nrm; mub[0] = m0; mub[1] = m1; mub[2] = m2; mub[3] = m3; }
+            }
+            for (int j = o0; j < o1; ++j) S.x[L.il(k) + j] = (j == jb) ? lb : 0.0;
+            for (int q = 0; q < 4; ++q) S.x[L.imu(k) + 4 * i + q] = mub[q];
+        }
+    }
+}
+
 // zwarm != nullptr: start from that primal vector moved one stage forward (last stage repeated; obca_set_warm_start); otherwise
 // start `kind` of the ladder (csrc/obca_device.h: OBCA_KIND_*; the window as a trajectory: oracle/ipm_dense.py:window_start).
 // mu0: the barrier parameter the pass begins with; iter_cap: its iteration limit beside max_iter_* (the caller's patience)
@@ -1020,6 +1093,7 @@ LPI_FN Out solve_instance(const Lay& L, const Sh& S, const Inst& in, const ObcaO
         // x0 start: every pose at x0 -- where IPOPT's first full Newton step lands from the all-zero start (the dynamics
         // linearised at v = 0 read x_{k+1} = x_k, the initial condition x_0 = x0)
         if (kind == OBCA_KIND_X0) for (int k = 0; k <= L.N; ++k) for (int j = 0; j < 3; ++j) S.x[L.ip(k) + j] = in.x0[j];
+        if (kind == OBCA_KIND_DODGE_R || kind == OBCA_KIND_DODGE_L) dodge_start(L, S, in, kind == OBCA_KIND_DODGE_R ? -1.0 : 1.0);
         if (from_window) {              // poses of the reference window, inputs by differences
             const int N1 = L.N + 1;
             for (int k = 0; k <= L.N; ++k)
@@ -1477,32 +1551,49 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
             iters += o.iters; nfact += o.nfact;
         }
     }
-    o.iters = iters; o.nfact = nfact;
-    if (A.warm_z != nullptr && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE)) {
-        double* zp = A.warm_z + inst * (size_t)A.n_max;
-        for (int t = 0; t < L.n; ++t) zp[t] = S.x[t];
+    // what a pass leaves behind goes to the caller's buffers
+    auto store = [&](const Out& r) {
+        if (A.warm_z != nullptr && (r.status == OBCA_STATUS_OK || r.status == OBCA_STATUS_ACCEPTABLE)) {
+            double* zp = A.warm_z + inst * (size_t)A.n_max;
+            for (int t = 0; t < L.n; ++t) zp[t] = S.x[t];
+        }
+        if (A.cert_z != nullptr) {
+            double* zc = A.cert_z + inst * (size_t)A.n_max;
+            for (int t = 0; t < L.n; ++t) zc[t] = S.x[t];
+        }
+        if (A.cert_y != nullptr) {
+            double* yc = A.cert_y + inst * (size_t)(A.R_max + 2 * L.npair);
+            const double isf = 1.0 / r.sf;
+            for (int q = 0; q < L.R; ++q) yc[q] = S.y[q] * isf;
+            for (int t = 0; t < 2 * L.npair; ++t) yc[L.R + t] = S.nu[t] * isf;
+        }
+        double* xo = A.xopt + inst * 3 * N1;
+        double* uo = A.uopt + inst * 2 * L.N;
+        for (int j = 0; j < 3; ++j) for (int k = 0; k < N1; ++k) xo[j * N1 + k] = S.x[L.ip(k) + j];
+        for (int j = 0; j < 2; ++j) for (int k = 0; k < L.N; ++k) uo[j * L.N + k] = S.x[L.iu(k) + j];
+        A.ts_opt[inst] = r.ts_opt;
+        A.status[inst] = r.status;
+        if (A.info) {
+            double* io = A.info + inst * 4;
+            io[0] = r.f; io[1] = r.elastic; io[2] = r.E0;
+        }
+    };
+    store(o);
+    // The dodge rung (csrc/obca_device.h: OBCA_KIND_DODGE_*): fixed-time problems on which every start of the order ended
+    // without a feasible point -- the window moved to the right, then to the left; both run, the feasible answer with the lower
+    // objective is the one that stays in the caller's buffers (the first pass's outputs are overwritten only by a better one)
+    if (O0.dodge && !L.free_T && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
+        bool have = false;
+        double fbest = 0.0;
+        for (int side = 0; side < 2; ++side) {
+            const Out r = solve_instance(L, S, in, O0, nullptr, OBCA_RESTART_MU, side == 0 ? OBCA_KIND_DODGE_R : OBCA_KIND_DODGE_L, O0.retry_iter);
+            iters += r.iters; nfact += r.nfact;
+            const bool ok = r.status == OBCA_STATUS_OK || r.status == OBCA_STATUS_ACCEPTABLE;
+            if (ok && (!have || r.f < fbest)) { store(r); have = true; fbest = r.f; }
+        }
     }
-    if (A.cert_z != nullptr) {
-        double* zc = A.cert_z + inst * (size_t)A.n_max;
-        for (int t = 0; t < L.n; ++t) zc[t] = S.x[t];
-    }
-    if (A.cert_y != nullptr) {
-        double* yc = A.cert_y + inst * (size_t)(A.R_max + 2 * L.npair);
-        const double isf = 1.0 / o.sf;
-        for (int r = 0; r < L.R; ++r) yc[r] = S.y[r] * isf;
-        for (int t = 0; t < 2 * L.npair; ++t) yc[L.R + t] = S.nu[t] * isf;
-    }
-    double* xo = A.xopt + inst * 3 * N1;
-    double* uo = A.uopt + inst * 2 * L.N;
-    for (int j = 0; j < 3; ++j) for (int k = 0; k < N1; ++k) xo[j * N1 + k] = S.x[L.ip(k) + j];
-    for (int j = 0; j < 2; ++j) for (int k = 0; k < L.N; ++k) uo[j * L.N + k] = S.x[L.iu(k) + j];
-    A.ts_opt[inst] = o.ts_opt;
-    A.status[inst] = o.status;
-    A.iters[inst] = o.iters;
-    if (A.info) {
-        double* io = A.info + inst * 4;
-        io[0] = o.f; io[1] = o.elastic; io[2] = o.E0; io[3] = (double)o.nfact;
-    }
+    A.iters[inst] = iters;
+    if (A.info) A.info[inst * 4 + 3] = (double)nfact;
 }
 
 }  // namespace lpi
