@@ -47,6 +47,11 @@ typedef struct obca_weights {
 
 /* everything else the reference passes per call and keeps constant over a rollout */
 typedef struct obca_params {
+    uint32_t struct_size;              /* sizeof(obca_params) of the header the CALLER was built against: set by
+                                          obca_params_init() (or by hand after zero-initialising).  Anything else -- a caller built
+                                          against another layout, a struct that was never initialised -- is answered with
+                                          OBCA_E_INVAL instead of being read field by field as something it is not          */
+    uint32_t reserved_;                /* 0                                                        */
     obca_weights free_time;            /* used by variant 4 (closed_loop.py:77-81)                */
     obca_weights fixed_time;           /* used by variants 6 and 8 (closed_loop.py:94-98)         */
     double xL[2], xU[2];               /* position box (theta is unbounded, obca.py:916)          */
@@ -67,8 +72,10 @@ typedef struct obca_params {
                                                    trial step; 0 = the default, negative = off              */
     /* The starts of a solve ("start ladder"; rule and measurements: oracle/ipm_dense.py:solve).  A solve
        that ends without a feasible point -- status 2, -1, -2, -3 -- is repeated from the next start of the order, inside the
-       same launch, until one start ends feasible or the order is exhausted; status, iteration and factorisation counts
-       returned are those of the whole sequence, the iterate returned is the last pass's.  The three starts:
+       same launch, until one start ends feasible or the order is exhausted; iteration and factorisation counts returned are
+       those of the whole sequence; status and iterate are those of the pass that ended feasible, otherwise those of the LAST pass
+       of the order (so after an exhausted ladder status -1 means "the last start hit its limit retry_iter", not that the first
+       one did; a first start that converged to an infeasible stationary point, status 2, is not reported).  The three starts:
          x0      every variable 0, Topt = 1 as the reference (src/obca.py:856), every pose at x0 -- the iterate IPOPT's first
                  Newton step reaches from the reference's all-zero start (the initial condition and the dynamics linearised
                  at v = 0 read x_k = x0); uses nothing but x0, like the reference's cold start
@@ -86,7 +93,30 @@ typedef struct obca_params {
                                                    it or crawl until max_iter); never above max_iter_*; with
                                                    single_start = 1 only max_iter_* applies                 */
     int32_t retry_iter;                /* [300 + 10 N]  iteration limit of every later start's passes; never above max_iter_* */
+    int32_t dodge;                     /* [on]    0 = the default (on), negative = off.  The last rung of the ladder, obca_mpc6 /
+                                                   obca_mpc8 only, after every start of the order (the one start with
+                                                   single_start = 1) ended without a feasible point: where the reference window
+                                                   runs head-on into an obstacle the penalty problem has a stationary point that is
+                                                   symmetric about the window (the plan brakes in front of the obstacle) and all
+                                                   three starts end there although a plan around the obstacle exists -- steps 21-25
+                                                   of the reference's own demo11 run, where IPOPT drives around.  Two more passes
+                                                   start from the window moved 3 m to the right and to the left of the direction of
+                                                   travel (ramped in over three stages; lambda, mu on the separating half-space);
+                                                   both run, the feasible answer with the lower objective is returned; their
+                                                   iterations are added to `iters`.  A failed rung leaves the answer of the order's
+                                                   last pass.                                                  */
+    int32_t terminal_screen;           /* [on]    0 = the default (on), negative = off.  obca_mpc6 whose terminal set
+                                                   x_N >= term[0] no trajectory can reach -- the first step's heading is x0's, the
+                                                   speeds are bounded by uL / uU and, from u0, by the acceleration rows; margin for
+                                                   elastic variables of size feas_tol on the rows involved -- is not run: status
+                                                   OBCA_STATUS_INFEASIBLE, iters 0, xopt = x0 at every stage, uopt = 0,
+                                                   info = (0, shortfall in metres, 0, 0).  The reference's closed loop asks for
+                                                   x0 + 5 m in N_fix steps of exactly 1 m at full speed, so after the first dodge
+                                                   four of five failing obca_mpc6 calls are of this kind (tests/test_terminal_screen.py) */
 } obca_params;
+
+/* zero-fills *p and sets struct_size: the one way to start filling an obca_params */
+void obca_params_init(obca_params* p);
 
 /* obca_params.start_order */
 enum {
@@ -343,7 +373,8 @@ int obca_rasterise_batch(const double* boxes, int32_t B, int32_t K, double resol
                          uint8_t* grid, void* hip_stream);
 
 const char* obca_strerror(int code);
-/* "obca_mpc 0.4 (gfx950)": 0.2 = the start ladder (start_order / single_start / patience / retry_iter replace restart); 0.3 = second
+/* "obca_mpc 0.5 (gfx950)": 0.5 = obca_params.struct_size (first member; obca_params_init), the dodge rung and the terminal-set screen;
+ * 0.2 = the start ladder (start_order / single_start / patience / retry_iter replace restart); 0.3 = second
  * level of the penalty escalation, compile-time-shape instantiations, obca_rollouts_queue_mode; 0.4 = OBCA_START_DEFAULT per variant
  * (OBCA_START_X0_FIRST moved from 0 to 3) */
 const char* obca_version(void);

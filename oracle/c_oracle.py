@@ -18,7 +18,9 @@ class OracleParams(ctypes.Structure):
                 ("feas_tol", ctypes.c_double), ("max_iter_free", ctypes.c_int), ("max_iter_fixed", ctypes.c_int),
                 ("max_soc", ctypes.c_int),          # 0 = IPOPT's default (4 second-order-correction trials), < 0 = off
                 # as obca_params (include/obca_mpc.h): the start ladder
-                ("start_order", ctypes.c_int), ("single_start", ctypes.c_int), ("patience", ctypes.c_int), ("retry_iter", ctypes.c_int)]
+                ("start_order", ctypes.c_int), ("single_start", ctypes.c_int), ("patience", ctypes.c_int), ("retry_iter", ctypes.c_int),
+                # 0 = the default (on), negative = off: the dodge rung of the ladder, the closed-form terminal-set screen of obca_mpc6
+                ("dodge", ctypes.c_int), ("terminal_screen", ctypes.c_int)]
 
 START_ORDERS = {"default": 0, "x0": 3, "window": 1, "zeros": 2}
 
@@ -66,9 +68,12 @@ def default_params(**kw):
     p.max_soc = int(kw.get("max_soc", 0))
     order = kw.get("start_order", 0)
     p.start_order = int(START_ORDERS.get(order, order))
-    p.single_start = int(bool(kw.get("single_start", 0)))
+    ss = kw.get("single_start", 0)
+    p.single_start = int(ss) if isinstance(ss, (int, np.integer)) and not isinstance(ss, bool) else int(bool(ss))     # (an out-of-range integer reaches the library as it is)
     p.patience = int(kw.get("patience", 0))
     p.retry_iter = int(kw.get("retry_iter", 0))
+    p.dodge = 0 if kw.get("dodge", True) else -1
+    p.terminal_screen = 0 if kw.get("terminal_screen", True) else -1
     return p
 
 
@@ -89,8 +94,10 @@ def solve_batch(variant, N, m, x0, u0, xref, A, b, Ts, term=None, params=None, t
     out = dict(xopt=np.zeros((B, 3, N + 1)), uopt=np.zeros((B, 2, N)), ts_opt=np.zeros(B),
                status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), info=np.zeros((B, 4)))
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    lib.obca_oracle_solve_batch(ctypes.c_int(N), ctypes.c_int(len(m)), marr, ptr(var), ctypes.c_int(B), ptr(x0), ptr(u0),
+    rc = lib.obca_oracle_solve_batch(ctypes.c_int(N), ctypes.c_int(len(m)), marr, ptr(var), ctypes.c_int(B), ptr(x0), ptr(u0),
                                 ptr(xref), ptr(A), ptr(b), ptr(Ts), ptr(term), ctypes.byref(params), ptr(out["xopt"]),
                                 ptr(out["uopt"]), ptr(out["ts_opt"]), ptr(out["status"]), ptr(out["iters"]),
                                 ptr(out["info"]), ctypes.c_int(threads))
+    if rc != 0:
+        raise ValueError("obca_oracle_solve_batch: invalid start options (return code %d)" % rc)
     return out

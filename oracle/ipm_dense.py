@@ -134,6 +134,10 @@ WINDOW_SPEED_FRAC = 0.9
 KIND_X0, KIND_WINDOW, KIND_ZEROS = 0, 1, 2
 START_ORDERS = {1: (KIND_WINDOW, KIND_X0, KIND_ZEROS), 2: (KIND_ZEROS, KIND_WINDOW, KIND_X0), 3: (KIND_X0, KIND_WINDOW, KIND_ZEROS)}
 ORDER_NAMES = {"default": 0, "x0": 3, "window": 1, "zeros": 2}
+# the dodge rung (csrc/obca_device.h: OBCA_KIND_DODGE_R / _L, OBCA_DODGE_OFFSET, OBCA_DODGE_RAMP)
+KIND_DODGE_R, KIND_DODGE_L = 3, 4
+DODGE_OFFSET = 3.0
+DODGE_RAMP = 3
 
 
 def retry_iter(N):
@@ -181,6 +185,121 @@ def window_start(p):
     return z
 
 
+def dodge_start(p, side):
+    """The dodge starts of the ladder's last rung (fixed-time problems on which every start of the order ended without a
+    feasible point).  Where the reference window runs head-on into an obstacle the l1 penalty problem has a stationary point
+    that is symmetric about the window -- the plan brakes in front of the obstacle, the terminal set and the distance rows share
+    the violation -- and x0, window and zeros all end there although a plan around the obstacle exists (the reference's own
+    demo11 run, steps 21-25: IPOPT drives around, tests/test_reference_demo11.py).  side = -1 / +1: the window moved to the
+    right / left of the direction of travel by DODGE_OFFSET metres, ramped in over the first DODGE_RAMP stages; headings along
+    the moved poses (continued from x0's heading without a jump by 2 pi), inputs by differences clipped to their box, the
+    free-time scale as window_start's; lambda, mu of every (stage, obstacle) pair: the half-space row with the largest gap to
+    the car at that pose, lambda = 1 / ||A_j|| on it, mu from the rotation equalities G'mu = -R A'lambda."""
+    N = p.N
+    z = np.zeros(p.n)
+    base = p.xref.copy()
+    base[:, 0] = p.x0
+    pts = base.copy()
+    for k in range(1, N + 1):
+        kb = min(k + 1, N)
+        ax, ay = base[0, kb] - base[0, k - 1], base[1, kb] - base[1, k - 1]
+        ln = math.sqrt(ax * ax + ay * ay)
+        th = p.xref[2, k]
+        nx, ny = (-ay / ln, ax / ln) if ln > 1e-9 else (-math.sin(th), math.cos(th))
+        w = side * DODGE_OFFSET * (k / DODGE_RAMP if k < DODGE_RAMP else 1.0)
+        pts[0, k] = base[0, k] + w * nx
+        pts[1, k] = base[1, k] + w * ny
+    pts[2, 0] = p.x0[2]
+    for k in range(1, N + 1):
+        prev = pts[2, k - 1]
+        th = prev
+        if k < N:
+            ddx, ddy = pts[0, k + 1] - pts[0, k], pts[1, k + 1] - pts[1, k]
+            if ddx * ddx + ddy * ddy > 1e-18:
+                d = math.atan2(ddy, ddx) - prev
+                d -= 2.0 * math.pi * math.floor(d / (2.0 * math.pi) + 0.5)
+                th = prev + d
+        pts[2, k] = th
+    T = 1.0
+    if p.variant == 4:
+        length = 0.0
+        for k in range(N):
+            length += math.sqrt((pts[0, k + 1] - pts[0, k]) ** 2 + (pts[1, k + 1] - pts[1, k]) ** 2)
+        T = min(max(1.0, length / (N * WINDOW_SPEED_FRAC * p.uU[0] * p.Ts)), max(1.0, p.Tmax))
+        z[p.iT()] = T
+    h = p.Ts * T
+    for k in range(N + 1):
+        z[p.ip(k):p.ip(k) + 3] = pts[:, k]
+        if k < N:
+            d = pts[:, k + 1] - pts[:, k]
+            z[p.iu(k)] = min(max(math.sqrt(d[0] * d[0] + d[1] * d[1]) / h, p.uL[0]), p.uU[0])
+            z[p.iu(k) + 1] = min(max(d[2] / h, p.uL[1]), p.uU[1])
+    for k in range(N + 1):
+        th = pts[2, k]
+        ct, st = math.cos(th), math.sin(th)
+        tx, ty = pts[0, k] + ct * p.off, pts[1, k] + st * p.off
+        ks = 0 if p.variant == 4 else k                      # obca_mpc4 reads the rows of step 0 only (SURVEY A.3 q5)
+        for i in range(p.nObs):
+            o0, o1 = p.off_m[i], p.off_m[i + 1]
+            best = None
+            for j in range(o0, o1):
+                a0, a1 = p.A[ks, j]
+                nrm = math.sqrt(a0 * a0 + a1 * a1)
+                if not nrm > 0.0:
+                    continue
+                v0, v1 = a0 / nrm, a1 / nrm
+                r0, r1 = ct * v0 + st * v1, -st * v0 + ct * v1
+                mu = (max(-r0, 0.0), max(-r1, 0.0), max(r0, 0.0), max(r1, 0.0))
+                gap = -(p.g[0] * mu[0] + p.g[1] * mu[1] + p.g[2] * mu[2] + p.g[3] * mu[3]) + (a0 * tx + a1 * ty - p.b[ks, j]) / nrm
+                if best is None or gap > best[0]:
+                    best = (gap, j, 1.0 / nrm, mu)
+            if best is not None:
+                z[p.il(k) + best[1]] = best[2]
+                z[p.imu(k) + 4 * i:p.imu(k) + 4 * i + 4] = best[3]
+    return z
+
+
+def terminal_set_shortfall(p, feas_tol=None):
+    """Closed-form screen of obca_mpc6 (csrc/obca_device.h: obca_terminal_shortfall): by how much NO trajectory the rows allow can
+    reach the terminal set's x_N >= term[0] (src/obca.py:1465).  x_0 = x0 and the heading of the first step is x0's; the speeds are
+    bounded by the input box and, from u0, by the acceleration rows (src/obca.py:928-939):
+        vhi_k = min(uU, vhi_{k-1} + a Ts),  vlo_k = max(uL, vlo_{k-1} - a Ts),  vhi_{-1} = vlo_{-1} = u0[0],  a = 0.6
+        x_N - x_0 <= Ts max(vhi_0 cos th0, vlo_0 cos th0) + Ts sum_{k >= 1} max(|vhi_k|, |vlo_k|),   x_N <= xU
+    Returns term[0] - (largest reachable x_N) - margin, where the margin is everything elastic variables of size feas_tol on the
+    rows involved can add (initial state, N dynamics rows, the terminal row, N input-box rows, the acceleration rows, whose
+    slack accumulates): feas_tol (N + 2 + N Ts + Ts^2 N (N + 1) / 2), doubled.  Positive: the solve would end 'infeasible'
+    whatever the obstacles do -- it is not run (status 2, zero iterations, the x0 start as the iterate).  The closed loop meets
+    this constantly: its terminal set is x0 + 5 (src/closed_loop.py:371) and N_fix Ts_opt uU = 5.000 m exactly while the car
+    follows the 1 m lattice path at full speed, so after the first dodge (heading != 0, or a braked step) obca_mpc6 cannot
+    succeed and obca_mpc8 answers (src/closed_loop.py:393-398)."""
+    if p.variant != 6:
+        return -math.inf
+    tol = DEFAULTS["feas_tol"] if feas_tol is None else feas_tol
+    h, a = p.Ts, 0.6                                   # oracle/obca_nlp.py: ACC_MAX[0]
+    vhi = vlo = p.u0[0]
+    reach = 0.0
+    c0 = math.cos(p.x0[2])
+    for k in range(p.N):
+        vhi = min(p.uU[0], vhi + a * h)
+        vlo = max(p.uL[0], vlo - a * h)
+        reach += h * (max(vhi * c0, vlo * c0) if k == 0 else max(abs(vhi), abs(vlo)))
+    xN = min(p.x0[0] + reach, p.xU[0])
+    margin = 2.0 * tol * (p.N + 2 + p.N * h + h * h * p.N * (p.N + 1) / 2.0)
+    return p.term[0] - xN - margin
+
+
+def _screened(p, shortfall):
+    """what a screened-out obca_mpc6 returns: status 'infeasible', no iteration, the x0 start as the iterate"""
+    r = Result()
+    r.x = x0_start(p)
+    r.status, r.iters, r.nfact, r.feas = STATUS_INFEASIBLE, 0, 0, False
+    r.f, r.elastic, r.E0, r.mu = 0.0, float(shortfall), 0.0, 0.0
+    r.xopt, r.uopt = p.unpack_xu(r.x)
+    r.Ts_opt = p.Ts
+    r.starts_used, r.restarted, r.screened = 0, False, True
+    return r
+
+
 def solve(p, opts=None, trace=None):
     """The elastic IPM run through the START LADDER (same rule in oracle/obca_oracle.c, csrc/obca_lpi_core.h:run_instance and
     the wave kernels; include/obca_mpc.h: start_order, single_start, patience, retry_iter):
@@ -203,6 +322,10 @@ def solve(p, opts=None, trace=None):
     ``no_escalation``.  With ``single_start`` a pass runs to ``max_iter``; otherwise the first start's passes stop after
     ``patience`` iterations, the later starts' after ``retry_iter``."""
     opts = dict(opts or {})
+    if p.variant == 6 and opts.get("terminal_screen", True):
+        short = terminal_set_shortfall(p, opts.get("feas_tol"))
+        if short > 0.0:
+            return _screened(p, short)
     order = opts.get("start_order", 0)
     order = ORDER_NAMES.get(order, order)
     if order == 0:                 # the default: x0 first for the free-time problem, the window first for the fixed-time ones
@@ -220,6 +343,8 @@ def solve(p, opts=None, trace=None):
         o = dict(opts, rho=rho, max_iter=cap)
         if kind == KIND_WINDOW:
             return _solve_once(p, dict(o, mu_init=RESTART_MU), trace, x_start=window_start(p))
+        if kind in (KIND_DODGE_R, KIND_DODGE_L):
+            return _solve_once(p, dict(o, mu_init=RESTART_MU, max_iter=min(max_v, ret)), trace, x_start=dodge_start(p, -1.0 if kind == KIND_DODGE_R else 1.0))
         return _solve_once(p, o, trace, x_start=x0_start(p) if kind == KIND_X0 else None)
 
     r = None
@@ -233,6 +358,20 @@ def solve(p, opts=None, trace=None):
                 r = _accumulate(run(s, kind, rho0 * mult), r)
         r.starts_used = s + 1
     r.restarted = r.starts_used > 1
+    # the dodge rung: fixed-time problems only, after the order is exhausted; both sides run, the feasible answer with the lower
+    # objective stays (a failed rung leaves the answer of the order's last pass, with the iterations added)
+    if p.variant != 4 and opts.get("dodge", True) and r.status not in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS):
+        best = None
+        it, nf = r.iters, getattr(r, "nfact", 0)
+        for kind in (KIND_DODGE_R, KIND_DODGE_L):
+            d = run(1, kind, rho0)
+            it, nf = it + d.iters, nf + getattr(d, "nfact", 0)
+            if d.status in (STATUS_OK, STATUS_ACCEPTABLE) and (best is None or d.f < best.f):
+                best = d
+        if best is not None:
+            best.starts_used, best.restarted = r.starts_used, True
+            r = best
+        r.iters, r.nfact, r.dodged = it, nf, best is not None
     return r
 
 

@@ -363,7 +363,9 @@ typedef struct {
 #define RETRY_ITER(N) (300 + 10 * (N)) /* csrc/obca_device.h: OBCA_RETRY_ITER */
 #define PATIENCE(N) (500 + 10 * (N)) /* csrc/obca_device.h: OBCA_PATIENCE */
 /* the three starts of the ladder and the three orders (include/obca_mpc.h: start_order; csrc/obca_device.h: OBCA_START_KIND) */
-enum { KIND_X0 = 0, KIND_WINDOW = 1, KIND_ZEROS = 2 };
+enum { KIND_X0 = 0, KIND_WINDOW = 1, KIND_ZEROS = 2, KIND_DODGE_R = 3, KIND_DODGE_L = 4 };   /* the last two: oracle/ipm_dense.py:dodge_start */
+#define DODGE_OFFSET 3.0          /* csrc/obca_device.h: OBCA_DODGE_OFFSET */
+#define DODGE_RAMP 3
 /* index: the EFFECTIVE order 1, 2, 3 (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER; 0 = default: 3 for obca_mpc4, 1 for obca_mpc6 / 8) */
 static const int START_ORDERS[4][3] = {{KIND_X0, KIND_WINDOW, KIND_ZEROS}, {KIND_WINDOW, KIND_X0, KIND_ZEROS}, {KIND_ZEROS, KIND_WINDOW, KIND_X0}, {KIND_X0, KIND_WINDOW, KIND_ZEROS}};
 #define KAPPA_MU 0.2
@@ -443,6 +445,72 @@ static int solve_one(Prob* p, const Opts* o, double* xout, double* uout, double*
             const double dth = x[ip(p, k + 1) + 2] - x[ip(p, k) + 2];
             x[iu(p, k)] = fmin(fmax(sqrt(ddx * ddx + ddy * ddy) / h, p->uL[0]), p->uU[0]);
             x[iu(p, k) + 1] = fmin(fmax(dth / h, p->uL[1]), p->uU[1]);
+        }
+    }
+    if (kind == KIND_DODGE_R || kind == KIND_DODGE_L) {      /* oracle/ipm_dense.py:dodge_start */
+        const int N1 = N + 1;
+        const double side = kind == KIND_DODGE_R ? -1.0 : 1.0;
+        for (int k = 0; k <= N; ++k) {
+            double px = k == 0 ? p->x0[0] : p->xref[0 * N1 + k], py = k == 0 ? p->x0[1] : p->xref[1 * N1 + k];
+            if (k > 0) {
+                const int ka = k - 1, kb = k + 1 <= N ? k + 1 : N;
+                const double ax = p->xref[0 * N1 + kb] - (ka == 0 ? p->x0[0] : p->xref[0 * N1 + ka]);
+                const double ay = p->xref[1 * N1 + kb] - (ka == 0 ? p->x0[1] : p->xref[1 * N1 + ka]);
+                const double len = sqrt(ax * ax + ay * ay), th = p->xref[2 * N1 + k];
+                const double nx = len > 1e-9 ? -ay / len : -sin(th), ny = len > 1e-9 ? ax / len : cos(th);
+                const double w = side * DODGE_OFFSET * (k < DODGE_RAMP ? (double)k / DODGE_RAMP : 1.0);
+                px += w * nx; py += w * ny;
+            }
+            x[ip(p, k)] = px; x[ip(p, k) + 1] = py;
+        }
+        x[ip(p, 0) + 2] = p->x0[2];
+        for (int k = 1; k <= N; ++k) {
+            const double prev = x[ip(p, k - 1) + 2];
+            double th = prev;
+            if (k < N) {
+                const double ddx = x[ip(p, k + 1)] - x[ip(p, k)], ddy = x[ip(p, k + 1) + 1] - x[ip(p, k) + 1];
+                if (ddx * ddx + ddy * ddy > 1e-18) {
+                    double d = atan2(ddy, ddx) - prev;
+                    d -= 6.283185307179586 * floor(d / 6.283185307179586 + 0.5);
+                    th = prev + d;
+                }
+            }
+            x[ip(p, k) + 2] = th;
+        }
+        if (p->freeT) {
+            double len = 0.0;
+            for (int k = 0; k < N; ++k) {
+                const double ddx = x[ip(p, k + 1)] - x[ip(p, k)], ddy = x[ip(p, k + 1) + 1] - x[ip(p, k) + 1];
+                len += sqrt(ddx * ddx + ddy * ddy);
+            }
+            x[iT(p)] = fmin(fmax(1.0, len / (N * WINDOW_SPEED_FRAC * p->uU[0] * p->Ts)), fmax(1.0, p->Tmax));
+        }
+        const double h = p->Ts * (p->freeT ? x[iT(p)] : 1.0);
+        for (int k = 0; k < N; ++k) {
+            const double ddx = x[ip(p, k + 1)] - x[ip(p, k)], ddy = x[ip(p, k + 1) + 1] - x[ip(p, k) + 1];
+            const double dth = x[ip(p, k + 1) + 2] - x[ip(p, k) + 2];
+            x[iu(p, k)] = fmin(fmax(sqrt(ddx * ddx + ddy * ddy) / h, p->uL[0]), p->uU[0]);
+            x[iu(p, k) + 1] = fmin(fmax(dth / h, p->uL[1]), p->uU[1]);
+        }
+        for (int k = 0; k <= N; ++k) {
+            const double th = x[ip(p, k) + 2], ct = cos(th), st = sin(th);
+            const double tx = x[ip(p, k)] + ct * p->off, ty = x[ip(p, k) + 1] + st * p->off;
+            for (int i = 0; i < p->nO; ++i) {
+                const int o0 = p->offm[i], o1 = p->offm[i + 1];
+                int jb = o0;
+                double gb = -INF, mub[4] = {0, 0, 0, 0}, lb_ = 0.0;
+                for (int j = o0; j < o1; ++j) {
+                    const double a0 = p->A[((size_t)k * p->M + j) * 2], a1 = p->A[((size_t)k * p->M + j) * 2 + 1];
+                    const double nrm = sqrt(a0 * a0 + a1 * a1);
+                    if (!(nrm > 0.0)) continue;
+                    const double v0 = a0 / nrm, v1 = a1 / nrm, r0 = ct * v0 + st * v1, r1 = -st * v0 + ct * v1;
+                    const double m0 = fmax(-r0, 0.0), m1 = fmax(-r1, 0.0), m2 = fmax(r0, 0.0), m3 = fmax(r1, 0.0);
+                    const double gap = -(p->g[0] * m0 + p->g[1] * m1 + p->g[2] * m2 + p->g[3] * m3) + (a0 * tx + a1 * ty - p->b[(size_t)k * p->M + j]) / nrm;
+                    if (gap > gb) { gb = gap; jb = j; lb_ = 1.0 / nrm; mub[0] = m0; mub[1] = m1; mub[2] = m2; mub[3] = m3; }
+                }
+                for (int j = o0; j < o1; ++j) x[il(p, k) + j] = j == jb ? lb_ : 0.0;
+                for (int q = 0; q < 4; ++q) x[imu(p, k) + 4 * i + q] = mub[q];
+            }
         }
     }
     /* scaling */
@@ -799,6 +867,7 @@ typedef struct {
     int max_iter_free, max_iter_fixed;
     int max_soc;                            /* 0 = IPOPT's default (4), negative = off */
     int start_order, single_start, patience, retry_iter;     /* as obca_params (include/obca_mpc.h) */
+    int dodge, terminal_screen;                              /* likewise: 0 = the default (on), negative = off */
 } OracleParams;
 
 static void sym(double* d, const double* s, int k) { for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) d[k * a + b] = 0.5 * (s[k * a + b] + s[k * b + a]); }
@@ -812,6 +881,8 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
     int M = 0;
     for (int i = 0; i < n_obs; ++i) M += m[i];
     (void)threads;
+    /* as csrc/obca_device.h: obca_resolve_starts -- what obca_solve_batch answers with OBCA_E_INVAL */
+    if (prm->start_order < 0 || prm->start_order > 3 || prm->single_start < 0 || prm->single_start > 1) return -22;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
 #endif
@@ -855,7 +926,7 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         /* the start ladder (oracle/ipm_dense.py:solve): the starts of the order until one ends at a feasible point; obca_mpc4 that
            converged with elastic variables left repeats the same start with rho x 100 and, if elastic variables still remain, with rho x 1000
            (the next start begins at the base penalty) */
-        const int order0 = prm->start_order >= 0 && prm->start_order <= 3 ? prm->start_order : 0;
+        const int order0 = prm->start_order;
         const int order = order0 != 0 ? order0 : ((p.variant == 4 || prm->single_start) ? 3 : 1);
         const int nstarts = prm->single_start ? 1 : 3;
         const int max_iter_v = p.freeT ? o.max_iter_free : o.max_iter_fixed;
@@ -865,6 +936,25 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         int it_sum = 0;
         double nf_sum = 0.0;
         status[q] = ST_MAXITER;
+        if (p.variant == 6 && prm->terminal_screen >= 0) {        /* oracle/ipm_dense.py:terminal_set_shortfall */
+            double vhi = p.u0[0], vlo = p.u0[0], reach = 0.0;
+            const double c0 = cos(p.x0[2]);
+            for (int k = 0; k < N; ++k) {
+                vhi = fmin(p.uU[0], vhi + 0.6 * p.Ts);
+                vlo = fmax(p.uL[0], vlo - 0.6 * p.Ts);
+                reach += p.Ts * (k == 0 ? fmax(vhi * c0, vlo * c0) : fmax(fabs(vhi), fabs(vlo)));
+            }
+            const double xN = fmin(p.x0[0] + reach, p.xU[0]);
+            const double sh = p.term[0] - xN - 2.0 * o.feas_tol * (N + 2 + N * p.Ts + p.Ts * p.Ts * N * (N + 1) / 2.0);
+            if (sh > 0.0) {
+                for (int j = 0; j < 3; ++j) for (int k = 0; k <= N; ++k) xo[j * (N + 1) + k] = p.x0[j];
+                for (int t = 0; t < 2 * N; ++t) uo[t] = 0.0;
+                ts_opt[q] = p.Ts; status[q] = ST_INFEASIBLE; iters[q] = 0;
+                if (io) { io[0] = 0.0; io[1] = sh; io[2] = 0.0; io[3] = 0.0; }
+                free(Arep); free(brep);
+                continue;
+            }
+        }
         for (int s = 0; s < nstarts; ++s) {
             if (s > 0 && (status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) break;
             const int kind = START_ORDERS[order][s];
@@ -878,6 +968,27 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
                 status[q] = solve_one(&p, &o2, xo, uo, ts_opt + q, iters + q, io, kind, mu0, cap);
                 it_sum += iters[q]; if (io) nf_sum += io[3];
             }
+        }
+        /* the dodge rung (oracle/ipm_dense.py:solve): fixed-time problems after the order is exhausted; both sides run, the
+           feasible answer with the lower objective stays */
+        if (p.variant != 4 && prm->dodge >= 0 && !(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
+            double* xt_ = (double*)malloc(sizeof(double) * (3 * (N + 1) + 2 * N));
+            double* ut_ = xt_ + 3 * (N + 1);
+            int have = 0;
+            double fbest = 0.0;
+            for (int side = 0; side < 2 && xt_; ++side) {
+                double tst, inf_[4];
+                int itr;
+                const int st = solve_one(&p, &o, xt_, ut_, &tst, &itr, inf_, side == 0 ? KIND_DODGE_R : KIND_DODGE_L, RESTART_MU, ret);
+                it_sum += itr; nf_sum += inf_[3];
+                if ((st == ST_OK || st == ST_ACCEPTABLE) && (!have || inf_[0] < fbest)) {
+                    memcpy(xo, xt_, sizeof(double) * 3 * (N + 1)); memcpy(uo, ut_, sizeof(double) * 2 * N);
+                    ts_opt[q] = tst; status[q] = st;
+                    if (io) { io[0] = inf_[0]; io[1] = inf_[1]; io[2] = inf_[2]; }
+                    have = 1; fbest = inf_[0];
+                }
+            }
+            free(xt_);
         }
         iters[q] = it_sum;
         if (io) io[3] = nf_sum;

@@ -11,6 +11,7 @@ struct HostParams {            // same field order as oracle/c_oracle.py:OracleP
     int max_iter_free, max_iter_fixed;
     int max_soc;
     int start_order, single_start, patience, retry_iter;     // as obca_params (include/obca_mpc.h)
+    int dodge, terminal_screen;                              // 0 = the default (on), negative = off
 };
 
 static void sym(double* d, const double* s, int k) {
@@ -49,8 +50,7 @@ extern "C" int lpi_host_solve_batch_warm(int N, int n_obs, const int* m, const i
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
     L.prm.opt.max_soc = p->max_soc == 0 ? OBCA_MAX_SOC : (p->max_soc < 0 ? 0 : p->max_soc);
-    if (!obca_resolve_starts(&L.prm.opt, p->start_order, p->single_start, p->patience, p->retry_iter, N)) return -22;
-    if (getenv("OBCA_DODGE_EXPERIMENT")) L.prm.opt.dodge = atoi(getenv("OBCA_DODGE_EXPERIMENT"));
+    if (!obca_resolve_starts(&L.prm.opt, p->start_order, p->single_start, p->patience, p->retry_iter, N, p->dodge, p->terminal_screen)) return -22;
     const lpi::Carve c = lpi::carve(N, n_obs, M, L.n_max, L.R_max);
     // The device lays the workspace out [element][instance] (stride = batch) so that a wave's accesses coalesce.  On the
     // host the same indexing is exercised with stride = B when B <= 8; larger batches give every OpenMP thread one

@@ -76,6 +76,8 @@ class LpiObca:
         self.calls = []
         self.start_order = "default"       # as the drop-in obca class (…_amd/obca.py): "default" | "x0" | "window" | "zeros"
         self.single_start = False
+        self.dodge = True
+        self.terminal_screen = True
         self.engine = engine               # "lpi": structured core (csrc/obca_lpi_core.h); "oracle": dense C oracle (oracle/obca_oracle.c)
 
     def _solve(self, variant, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, term=None, single_start=False):
@@ -83,7 +85,7 @@ class LpiObca:
         from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import pack_reference_call
         m, x0a, u0a, xr, A, b, ts, tm = pack_reference_call(variant, Ts, N, x0, xref, nObs, vObs, AObs, bObs, u0, term)
         kw = dict(xL=xL[:2], xU=xU[:2], uL=uL, uU=uU, ego=ego, dmin=dmin)
-        kw.update(start_order=self.start_order, single_start=bool(single_start or self.single_start))
+        kw.update(start_order=self.start_order, single_start=bool(single_start or self.single_start), dodge=self.dodge, terminal_screen=self.terminal_screen)
         if variant == 4:
             kw.update(Qf=Q, Pf=P, R1f=R[0], R2f=R[1])
         else:

@@ -51,7 +51,7 @@ def test_structured_equals_dense(nlp_golden, idx):
             seen.append(d["it"])
             compare(p, d)
 
-    ipm_dense.solve(p, dict(probe=probe, max_iter=41, max_soc=0, single_start=True, start_order="zeros"))
+    ipm_dense.solve(p, dict(probe=probe, max_iter=41, max_soc=0, single_start=True, start_order="zeros", dodge=False))
     assert len(seen) >= 5
 
 
@@ -68,7 +68,7 @@ def test_two_sided_sweep_equals_dense(nlp_golden, idx):
                 compare(p, d, split=m)
             seen.append(d["it"])
 
-    ipm_dense.solve(p, dict(probe=probe, max_iter=26, max_soc=0, single_start=True, start_order="zeros"))
+    ipm_dense.solve(p, dict(probe=probe, max_iter=26, max_soc=0, single_start=True, start_order="zeros", dodge=False))
     assert len(seen) == 3
 
 
@@ -157,5 +157,5 @@ def test_kernel_form_of_the_forward_stage(nlp_golden, idx):
         if d["it"] in (0, 3, 20):
             compare(p, d, split=p.N - 1, kernel_check=partial(_forward_stage_as_the_kernel_does_it, worst=worst))
 
-    ipm_dense.solve(p, dict(probe=probe, max_iter=21, max_soc=0, single_start=True, start_order="zeros"))
+    ipm_dense.solve(p, dict(probe=probe, max_iter=21, max_soc=0, single_start=True, start_order="zeros", dodge=False))
     assert len(worst) == 3 * (p.N - 1) and max(worst) < 1e-10

@@ -49,11 +49,19 @@ def test_single_start_ends_where_the_first_start_ends(nlp_golden, order):
     """obca_params.single_start = 1: the first start of the order alone -- on the witness it ends at the infeasible stationary
     point (status 2), which is what a driver with its own fallback (obca_mpc8 after obca_mpc6) asks for"""
     case = [c for c in nlp_golden if c["name"] == "demo1_dyn_mpc6"][0]
-    r = ipm_dense.solve(build(case), dict(start_order=order, single_start=True))
+    r = ipm_dense.solve(build(case), dict(start_order=order, single_start=True, dodge=False))
     assert r.status == ipm_dense.STATUS_INFEASIBLE and not r.restarted
-    args = _packed(case, start_order=order, single_start=1)
+    args = _packed(case, start_order=order, single_start=1, dodge=False)
     assert c_oracle.solve_batch(*args)["status"][0] == 2
     assert native_build.lpi_solve(*args)["status"][0] == 2
+    # ... and with the ladder's last rung (the default) the same call finds a plan around the box: the dodge passes follow a
+    # single start as well -- what the reference's demo11 run needs from the closed loop's obca_mpc6
+    args = _packed(case, start_order=order, single_start=1)
+    r = ipm_dense.solve(build(case), dict(start_order=order, single_start=True))
+    c, g = c_oracle.solve_batch(*args), native_build.lpi_solve(*args)
+    assert r.status == 0 and r.dodged and c["status"][0] == 0 and g["status"][0] == 0
+    np.testing.assert_allclose(c["xopt"][0], r.xopt, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(g["xopt"][0], r.xopt, rtol=0, atol=1e-8)
 
 
 @pytest.mark.parametrize("order", ["default", "x0", "window", "zeros"])
@@ -78,7 +86,7 @@ def test_iteration_limits_of_the_ladder(nlp_golden):
     infeasible stationary point, the window start 49 to the plan."""
     case = [c for c in nlp_golden if c["name"] == "demo1_dyn_mpc6"][0]
     for engine in (c_oracle.solve_batch, native_build.lpi_solve):
-        x0f = dict(start_order="x0")                                             # (x0 first: the default order starts obca_mpc6 at the window)
+        x0f = dict(start_order="x0", dodge=False)                                # (x0 first: the default order starts obca_mpc6 at the window; the rung after the order is switched off: its passes would add their own retry_iter iterations)
         it0 = engine(*_packed(case, single_start=1, **x0f))["iters"][0]        # the x0 start alone, to its end
         o = engine(*_packed(case, patience=20, **x0f))                           # first start abandoned after 20 iterations
         assert o["status"][0] == 0 and 20 < o["iters"][0] < it0 + 49
@@ -149,7 +157,7 @@ def test_c3_gated_batch_with_the_ladder_structured_core_against_dense_oracle():
     N, B = 8, 32
     b = sc.make_batch_c3(B, N, gated=True)
     args = (b["variant"], N, b["m"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"])
-    cold = native_build.lpi_solve(*args, params=c_oracle.default_params(single_start=1, start_order="x0"))     # the x0 start alone
+    cold = native_build.lpi_solve(*args, params=c_oracle.default_params(single_start=1, start_order="x0", dodge=False))     # the x0 start alone
     got = native_build.lpi_solve(*args, cert=True)                     # default: the window first for obca_mpc6, then x0, then zeros
     ref = c_oracle.solve_batch(*args, threads=8)
     ok_cold, ok = np.isin(cold["status"], (0, 1)), np.isin(got["status"], (0, 1))

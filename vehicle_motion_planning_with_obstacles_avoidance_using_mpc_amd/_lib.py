@@ -24,14 +24,21 @@ class ObcaWeights(ctypes.Structure):
 
 
 class ObcaParams(ctypes.Structure):
-    _fields_ = [("free_time", ObcaWeights), ("fixed_time", ObcaWeights),
+    """obca_params (include/obca_mpc.h).  A new instance is what obca_params_init leaves: all zero (= every default),
+    struct_size set."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
+                ("free_time", ObcaWeights), ("fixed_time", ObcaWeights),
                 ("xL", ctypes.c_double * 2), ("xU", ctypes.c_double * 2),
                 ("uL", ctypes.c_double * 2), ("uU", ctypes.c_double * 2),
                 ("ego", ctypes.c_double * 4), ("dmin", ctypes.c_double),
                 ("tol", ctypes.c_double), ("rho", ctypes.c_double), ("feas_tol", ctypes.c_double),
                 ("max_iter_free", ctypes.c_int32), ("max_iter_fixed", ctypes.c_int32), ("max_soc", ctypes.c_int32),
                 ("start_order", ctypes.c_int32), ("single_start", ctypes.c_int32), ("patience", ctypes.c_int32),
-                ("retry_iter", ctypes.c_int32)]
+                ("retry_iter", ctypes.c_int32), ("dodge", ctypes.c_int32), ("terminal_screen", ctypes.c_int32)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = ctypes.sizeof(ObcaParams)
 
 
 # obca_params.start_order (include/obca_mpc.h)
@@ -45,7 +52,7 @@ class ObcaRolloutDims(ctypes.Structure):
                 ("max_steps", ctypes.c_int32), ("device", ctypes.c_int32), ("N_fix", ctypes.c_int32)]
 
 
-EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version",
+EXPORTS = ("obca_create", "obca_destroy", "obca_solve_batch", "obca_lds_bytes", "obca_strerror", "obca_version", "obca_params_init",
            "obca_set_profile_buffer", "obca_set_mode", "obca_set_two_sided_sweep", "obca_rollouts_create", "obca_rollouts_destroy", "obca_rollouts_debug_stats", "obca_rollouts_debug_harness",
            "obca_rollouts_reset", "obca_rollouts_step", "obca_rollouts_read", "obca_rollouts_run",
            "obca_rollouts_set_mode", "obca_rollouts_queue_mode", "obca_set_shape_specialisation", "obca_shape_is_specialised", "obca_astar_batch", "obca_astar_workspace_bytes", "obca_primal_size", "obca_set_warm_start",

@@ -272,6 +272,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
         !iters || !out)
         return OBCA_E_INVAL;
     if (B < 0 || B > h->dims.max_batch) return OBCA_E_INVAL;
+    if (p->struct_size != (uint32_t)sizeof(obca_params)) return OBCA_E_INVAL;      // another layout, or never initialised (obca_params_init)
     ObcaLaunch& L = *out;
     memset(&L, 0, sizeof(L));
     L.B = B; L.N = h->dims.N; L.nO = h->dims.n_obs; L.M = h->M; L.n_max = h->n_max; L.R_max = h->R_max; L.inst_off = h->inst_off;
@@ -308,7 +309,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     L.prm.opt.max_iter_free = p->max_iter_free > 0 ? p->max_iter_free : 3000;
     L.prm.opt.max_iter_fixed = p->max_iter_fixed > 0 ? p->max_iter_fixed : 1000;
     L.prm.opt.max_soc = p->max_soc == 0 ? OBCA_MAX_SOC : (p->max_soc < 0 ? 0 : p->max_soc);
-    if (!obca_resolve_starts(&L.prm.opt, p->start_order, p->single_start, p->patience, p->retry_iter, h->dims.N)) return OBCA_E_INVAL;
+    if (!obca_resolve_starts(&L.prm.opt, p->start_order, p->single_start, p->patience, p->retry_iter, h->dims.N, p->dodge, p->terminal_screen)) return OBCA_E_INVAL;
     if (lds_bytes) *lds_bytes = h->lds_bytes;
     if (wave_ok) *wave_ok = h->wave_ok ? 1 : 0;
     return OBCA_OK;
@@ -394,4 +395,9 @@ extern "C" const char* obca_strerror(int code) {
     }
 }
 
-extern "C" const char* obca_version(void) { return "obca_mpc 0.4 (gfx950)"; }
+extern "C" const char* obca_version(void) { return "obca_mpc 0.5 (gfx950)"; }
+extern "C" void obca_params_init(obca_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->struct_size = (uint32_t)sizeof(*p);
+}

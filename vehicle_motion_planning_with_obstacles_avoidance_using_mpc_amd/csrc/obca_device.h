@@ -2,6 +2,7 @@
 #ifndef OBCA_DEVICE_H
 #define OBCA_DEVICE_H
 
+#include <math.h>
 #include <stdint.h>
 #include "../../include/obca_mpc.h"
 
@@ -72,6 +73,9 @@
 #define OBCA_KIND_DODGE_L 4
 #define OBCA_DODGE_OFFSET 3.0
 #define OBCA_DODGE_RAMP 3
+/* transient, kernel-internal: a feasible answer of the first dodge pass waiting for the second one (never returned to a caller) */
+#define OBCA_STATUS_DODGE_OK 3
+#define OBCA_STATUS_DODGE_ACC 4
 /* obca_params.start_order = OBCA_START_DEFAULT (0) means: x0 first for the free-time problem (obca_mpc4: one optimum on the bench
    workloads, and the x0 start needs nothing but x0), the reference window first for the fixed-time ones (obca_mpc6 / obca_mpc8: several
    local optima -- measured on 2048 gated instances at N = 20 the window start ends lower than x0 on 73-76 % of those both solve and
@@ -171,16 +175,38 @@ constexpr ObcaShapeSizes obca_shape_sizes(int N, int nO, int M) {
 
 struct ObcaWeightsDev { double Q[9], P[9], R1[4], R2[4]; };
 /* order: obca_params.start_order (validated); nstarts: 1 (single_start) or 3; patience / retry_iter: resolved (> 0) */
-struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, order, nstarts, patience, retry_iter, dodge; };
-/* the four start fields of obca_params -> their resolved form; false: start_order / single_start outside its range */
-static inline bool obca_resolve_starts(ObcaOptsDev* o, int start_order, int single_start, int patience, int retry_iter, int N) {
+struct ObcaOptsDev { double tol, rho, feas_tol; int32_t max_iter_free, max_iter_fixed, max_soc, order, nstarts, patience, retry_iter, dodge, screen, pad_; };
+/* the start fields of obca_params -> their resolved form; false: start_order / single_start outside its range.  dodge /
+   terminal_screen follow the zero-initialisation rule of obca_params: 0 = the default (on), negative = off */
+static inline bool obca_resolve_starts(ObcaOptsDev* o, int start_order, int single_start, int patience, int retry_iter, int N, int dodge = 0, int terminal_screen = 0) {
     if (start_order < OBCA_START_DEFAULT || start_order > OBCA_START_X0_FIRST || single_start < 0 || single_start > 1) return false;
     o->order = start_order;
     o->nstarts = single_start ? 1 : 3;
     o->patience = patience > 0 ? patience : OBCA_PATIENCE(N);
     o->retry_iter = retry_iter > 0 ? retry_iter : OBCA_RETRY_ITER(N);
-    o->dodge = 0;
+    o->dodge = dodge >= 0 ? 1 : 0;
+    o->screen = terminal_screen >= 0 ? 1 : 0;
+    o->pad_ = 0;
     return true;
+}
+/* Closed-form screen of obca_mpc6 (rule and derivation: oracle/ipm_dense.py:terminal_set_shortfall): by how much no trajectory
+   the rows allow can reach the terminal set's x_N >= termx -- the heading of the first step is x0's, the speeds are bounded by
+   the input box and, from u0, by the acceleration rows; the margin is what elastic variables of size feas_tol on the rows
+   involved can add.  > 0: the solve is not run (status OBCA_STATUS_INFEASIBLE, zero iterations, the x0 start as the iterate). */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline double obca_terminal_shortfall(int N, double Ts, const double* x0, double u0v, double uL0, double uU0, double xU0, double termx, double feas_tol) {
+    double vhi = u0v, vlo = u0v, reach = 0.0;
+    const double c0 = cos(x0[2]);
+    for (int k = 0; k < N; ++k) {
+        vhi = fmin(uU0, vhi + OBCA_ACC_MAX0 * Ts);
+        vlo = fmax(uL0, vlo - OBCA_ACC_MAX0 * Ts);
+        reach += Ts * (k == 0 ? fmax(vhi * c0, vlo * c0) : fmax(fabs(vhi), fabs(vlo)));
+    }
+    const double xN = fmin(x0[0] + reach, xU0);
+    const double margin = 2.0 * feas_tol * (N + 2 + N * Ts + Ts * Ts * N * (N + 1) / 2.0);
+    return termx - xN - margin;
 }
 struct ObcaParamsDev {
     ObcaWeightsDev free_time, fixed_time;

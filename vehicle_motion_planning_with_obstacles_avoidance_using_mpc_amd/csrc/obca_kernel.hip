@@ -1553,6 +1553,73 @@ __device__ __noinline__ void window_start_point(double* x, const double* xref, c
     }
 }
 
+// The dodge starts of the ladder's last rung (oracle/ipm_dense.py:dodge_start; csrc/obca_device.h: OBCA_KIND_DODGE_*; fixed-time
+// problems only): the window moved sideways by side * OBCA_DODGE_OFFSET (ramped in over OBCA_DODGE_RAMP stages), headings along the
+// moved poses, inputs by differences, lambda / mu of every (stage, obstacle) pair on the half-space row with the largest gap.
+// Rare, one lane, out of line (as window_start_point).  x is zero on entry.
+__device__ __noinline__ void dodge_start_point(double* x, const double* xref, const double* Aobs, const double* bobs, const int* offm,
+                                               const Inst* inp, int N, int NS, int M, int nO, double side) {
+    const Inst& in = *inp;
+    const int N1 = N + 1;
+    for (int k = 0; k <= N; ++k) {
+        double px = (k == 0) ? in.x0[0] : xref[0 * N1 + k], py = (k == 0) ? in.x0[1] : xref[1 * N1 + k];
+        if (k > 0) {
+            const int ka = k - 1, kb = k + 1 <= N ? k + 1 : N;
+            const double ax = xref[0 * N1 + kb] - ((ka == 0) ? in.x0[0] : xref[0 * N1 + ka]);
+            const double ay = xref[1 * N1 + kb] - ((ka == 0) ? in.x0[1] : xref[1 * N1 + ka]);
+            const double len = sqrt(ax * ax + ay * ay);
+            const double th = xref[2 * N1 + k];
+            const double nx = len > 1e-9 ? -ay / len : -sin(th), ny = len > 1e-9 ? ax / len : cos(th);
+            const double w = side * OBCA_DODGE_OFFSET * (k < OBCA_DODGE_RAMP ? (double)k / OBCA_DODGE_RAMP : 1.0);
+            px += w * nx; py += w * ny;
+        }
+        x[k * NS] = px; x[k * NS + 1] = py;
+    }
+    x[2] = in.x0[2];
+    for (int k = 1; k <= N; ++k) {
+        const double prev = x[(k - 1) * NS + 2];
+        double th = prev;
+        if (k < N) {
+            const double ddx = x[(k + 1) * NS] - x[k * NS], ddy = x[(k + 1) * NS + 1] - x[k * NS + 1];
+            if (ddx * ddx + ddy * ddy > 1e-18) {
+                double d = atan2(ddy, ddx) - prev;
+                d -= 6.283185307179586 * floor(d / 6.283185307179586 + 0.5);
+                th = prev + d;
+            }
+        }
+        x[k * NS + 2] = th;
+    }
+    const double h = in.Ts;
+    for (int k = 0; k < N; ++k) {
+        const double ddx = x[(k + 1) * NS] - x[k * NS], ddy = x[(k + 1) * NS + 1] - x[k * NS + 1];
+        const double dth = x[(k + 1) * NS + 2] - x[k * NS + 2];
+        x[k * NS + 3] = fmin(fmax(sqrt(ddx * ddx + ddy * ddy) / h, in.uL[0]), in.uU[0]);
+        x[k * NS + 4] = fmin(fmax(dth / h, in.uL[1]), in.uU[1]);
+    }
+    for (int k = 0; k <= N; ++k) {
+        const double th = x[k * NS + 2], ct = cos(th), st = sin(th);
+        const double tx = x[k * NS] + ct * in.off, ty = x[k * NS + 1] + st * in.off;
+        const int il = k * NS + (k < N ? 5 : 3);
+        for (int i = 0; i < nO; ++i) {
+            const int o0 = offm[i], o1 = offm[i + 1];
+            int jb = o0;
+            double gb = -INFINITY, m0b = 0.0, m1b = 0.0, m2b = 0.0, m3b = 0.0, lb = 0.0;
+            for (int j = o0; j < o1; ++j) {
+                const double a0 = Aobs[(k * M + j) * 2], a1 = Aobs[(k * M + j) * 2 + 1];
+                const double nrm = sqrt(a0 * a0 + a1 * a1);
+                if (!(nrm > 0.0)) continue;
+                const double v0 = a0 / nrm, v1 = a1 / nrm;
+                const double r0 = ct * v0 + st * v1, r1 = -st * v0 + ct * v1;
+                const double m0 = fmax(-r0, 0.0), m1 = fmax(-r1, 0.0), m2 = fmax(r0, 0.0), m3 = fmax(r1, 0.0);
+                const double gap = -(in.gego[0] * m0 + in.gego[1] * m1 + in.gego[2] * m2 + in.gego[3] * m3) + (a0 * tx + a1 * ty - bobs[k * M + j]) / nrm;
+                if (gap > gb) { gb = gap; jb = j; lb = 1.0 / nrm; m0b = m0; m1b = m1; m2b = m2; m3b = m3; }
+            }
+            for (int j = o0; j < o1; ++j) x[il + j] = (j == jb) ? lb : 0.0;
+            x[il + M + 4 * i] = m0b; x[il + M + 4 * i + 1] = m1b; x[il + M + 4 * i + 2] = m2b; x[il + M + 4 * i + 3] = m3b;
+        }
+    }
+}
+
 }  // namespace
 
 // ================================================================== the kernel
@@ -1648,8 +1715,47 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     // That is at most three starts x three penalties = OBCA_MAX_PASSES solves.  A genuinely infeasible problem stays
     // infeasible.  The state of the ladder lives in LDS (it must survive from call to call, and nothing of it may occupy a
     // register during the solve).
-    __shared__ int ladder_state[4];      // [0] escalation level of the current start (0: base penalty), [1] iterations, [2] factorisations so far, [3] index of the current start
+    // After the order's starts, fixed-time problems that still have no feasible point get the dodge rung (csrc/obca_device.h:
+    // OBCA_KIND_DODGE_R / _L): two more passes, BOTH run, the feasible answer with the lower objective stays in the caller's buffers.
+    // Between the two a feasible first answer is marked by the transient status OBCA_STATUS_DODGE_OK / _ACC (never seen by a
+    // caller: the second pass always replaces it), which the pass loops treat as "go on".
+    __shared__ int ladder_state[4];      // [0] escalation level of the current start (0: base penalty), [1] iterations, [2] factorisations so far, [3] index of the current start (nstarts, nstarts + 1: the dodge passes)
+    __shared__ double ladder_f;          // objective of a feasible first dodge pass
     const int order = OBCA_EFFECTIVE_ORDER(Ain.prm.opt.order, A.variant[inst], A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0), Ain.prm.opt.nstarts == 1);
+    // obca_mpc6 whose terminal set no trajectory can reach (csrc/obca_device.h: obca_terminal_shortfall) is not run: status
+    // 'infeasible', zero iterations, the x0 start as the iterate.  Checked at the head of every pass (a handful of scalar
+    // operations), so that the ladder does not climb on it either.
+    if (A.variant[inst] == 6 && Ain.prm.opt.screen) {
+        double x0s[3];
+        for (int j = 0; j < 3; ++j) x0s[j] = A.x0[(size_t)inst * 3 + j];
+        const double ts = A.Ts[inst];
+        const double sh = obca_terminal_shortfall(A.N, ts, x0s, A.u0[(size_t)inst * 2], Ain.prm.uL[0], Ain.prm.uU[0], Ain.prm.xU[0],
+                                                  A.term[(size_t)inst * 3], Ain.prm.opt.feas_tol);
+        if (sh > 0.0) {
+            if (first) {
+                const int N1 = A.N + 1;
+                double* xo = A.xopt + (size_t)inst * 3 * N1;
+                double* uo = A.uopt + (size_t)inst * 2 * A.N;
+                for (int t = lane; t < 3 * N1; t += NT) xo[t] = x0s[t / N1];
+                for (int t = lane; t < 2 * A.N; t += NT) uo[t] = 0.0;
+                if (A.cert_z != nullptr) {
+                    double* zc = A.cert_z + (size_t)inst * A.n_max;
+                    const int NSs = 5 + A.M + 4 * A.nO, nn = N1 * (3 + A.M + 4 * A.nO) + 2 * A.N;
+                    for (int t = lane; t < nn; t += NT) { const int k = t / NSs, q = t - k * NSs; zc[t] = q < 3 ? x0s[q] : 0.0; }
+                }
+                if (A.cert_y != nullptr) {
+                    double* yc = A.cert_y + (size_t)inst * (A.R_max + 2 * N1 * A.nO);
+                    const int Rv = 3 + 3 * A.N + 2 * N1 + 4 * A.N + 2 + N1 * (2 * A.nO + A.M + 4 * A.nO);      // rows of obca_mpc6
+                    for (int t = lane; t < Rv + 2 * N1 * A.nO; t += NT) yc[t] = 0.0;
+                }
+                if (lane == 0) {
+                    A.ts_opt[inst] = ts; A.status[inst] = OBCA_STATUS_INFEASIBLE; A.iters[inst] = 0;
+                    if (A.info) { double* io = A.info + (size_t)inst * 4; io[0] = 0.0; io[1] = sh; io[2] = 0.0; io[3] = 0.0; }
+                }
+            }
+            return;
+        }
+    }
     int start_s = 0, escalated = 0;
     if (!first) {
         const int st0 = __builtin_amdgcn_readfirstlane(A.status[inst]);     // wave-uniform: the flags below stay scalar
@@ -1657,10 +1763,10 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         escalated = __builtin_amdgcn_readfirstlane(ladder_state[0]);
         start_s = __builtin_amdgcn_readfirstlane(ladder_state[3]);
         if (A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE && escalated < OBCA_N_ESCALATIONS) ++escalated;
-        else { escalated = 0; if (++start_s >= Ain.prm.opt.nstarts) return; }
+        else { escalated = 0; if (++start_s >= Ain.prm.opt.nstarts + ((Ain.prm.opt.dodge && A.variant[inst] != 4) ? 2 : 0)) return; }
     }
     const double rho_mult = escalated ? OBCA_RHO_ESCALATION(escalated) : 1.0;
-    const int kind = OBCA_START_KIND(order, start_s);
+    const int kind = start_s < Ain.prm.opt.nstarts ? OBCA_START_KIND(order, start_s) : (start_s == Ain.prm.opt.nstarts ? OBCA_KIND_DODGE_R : OBCA_KIND_DODGE_L);
     const bool from_window = kind == OBCA_KIND_WINDOW;
 
     // ---- layout ------------------------------------------------------------------------------------
@@ -1791,7 +1897,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     ObcaOptsDev O;
     O.tol = Ain.prm.opt.tol; O.rho = Ain.prm.opt.rho * rho_mult; O.feas_tol = Ain.prm.opt.feas_tol; O.max_iter_free = Ain.prm.opt.max_iter_free; O.max_iter_fixed = Ain.prm.opt.max_iter_fixed; O.max_soc = Ain.prm.opt.max_soc;          // by value: A may live in HBM (fused closed-loop kernel)
     const int max_iter_v = L.free_T ? O.max_iter_free : O.max_iter_fixed;
-    const int max_iter_w = Ain.prm.opt.nstarts == 1 ? max_iter_v : (start_s == 0 ? Ain.prm.opt.patience : Ain.prm.opt.retry_iter);   // include/obca_mpc.h: patience
+    const int max_iter_w = start_s >= Ain.prm.opt.nstarts ? Ain.prm.opt.retry_iter : Ain.prm.opt.nstarts == 1 ? max_iter_v : (start_s == 0 ? Ain.prm.opt.patience : Ain.prm.opt.retry_iter);   // include/obca_mpc.h: patience
     const int max_iter = max_iter_v < max_iter_w ? max_iter_v : max_iter_w;
     const double acc_tol = L.free_T ? 1e-6 : 1e-8;                 // obca.py:1538
     const double acc_objchg = L.free_T ? 1e20 : 1e-6;
@@ -1822,6 +1928,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     SYNC();
     if (!warm && L.free_T && lane == 0) S.x[L.iT()] = 1.0;
     if (from_window && lane == 0) window_start_point(S.x, S.xref, &in, L.N, L.NS, L.free_T ? L.iT() : -1);
+    if (kind >= OBCA_KIND_DODGE_R && lane == 0) dodge_start_point(S.x, S.xref, S.Aobs, S.bobs, S.offm, &in, L.N, L.NS, L.M, L.nO, kind == OBCA_KIND_DODGE_R ? -1.0 : 1.0);
     // x0 start: where IPOPT's first full Newton step lands from the all-zero start (the dynamics linearised at v = 0 read
     // x_{k+1} = x_k, the initial condition x_0 = x0)
     if (kind == OBCA_KIND_X0 && !warm) for (int t = lane; t < 3 * (L.N + 1); t += NT) { const int k = t / 3; S.x[L.ip(k) + (t - 3 * k)] = in.x0[t - 3 * k]; }
@@ -1853,7 +1960,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     SYNC();
     f0 = eval_objective<true>(L, S, in, S.x, sf, lane);
     PUT(IV_F, f0);
-    double mu = from_window ? OBCA_RESTART_MU : (warm ? A.warm_mu : OBCA_MU_INIT);
+    double mu = (from_window || kind >= OBCA_KIND_DODGE_R) ? OBCA_RESTART_MU : (warm ? A.warm_mu : OBCA_MU_INIT);
     // rows: bounds, slacks with bound push, elastic variables on their 1-d central path
     {
         int bb = 0;
@@ -2382,11 +2489,32 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         A.iters = uni<U>(Ain.iters); A.info = uni<U>(Ain.info); A.warm_z = uni<U>(Ain.warm_z);
         A.cert_z = uni<U>(Ain.cert_z); A.cert_y = uni<U>(Ain.cert_y);
     }
-    if (A.warm_z != nullptr && (status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE)) {
+    // ---- dodge passes (ladder_state[3] >= nstarts): the answer in the caller's buffers is replaced only by a better one.
+    // keep: this pass's answer goes out.  status_out: what the status word becomes (-100: left as it is).
+    bool keep = true;
+    int status_out = status;
+    {
+        const int ls = __builtin_amdgcn_readfirstlane(ladder_state[3]), nst = Ain.prm.opt.nstarts;
+        if (ls >= nst) {
+            const bool ok = status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE;
+            if (ls == nst) {           // to the right: goes out if feasible, marked "one more pass to come"
+                keep = ok;
+                status_out = ok ? (status == OBCA_STATUS_OK ? OBCA_STATUS_DODGE_OK : OBCA_STATUS_DODGE_ACC) : -100;
+                if (ok && lane == 0) ladder_f = GET(IV_F) / sf;
+            } else {                   // to the left: goes out if feasible and better than a feasible first one
+                const int stp = __builtin_amdgcn_readfirstlane(A.status[inst]);
+                const bool pend = stp == OBCA_STATUS_DODGE_OK || stp == OBCA_STATUS_DODGE_ACC;
+                keep = ok && (!pend || GET(IV_F) / sf < ladder_f);
+                status_out = keep ? status : (pend ? (stp == OBCA_STATUS_DODGE_OK ? OBCA_STATUS_OK : OBCA_STATUS_ACCEPTABLE) : -100);
+            }
+        }
+    }
+    if (keep && A.warm_z != nullptr && (status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE)) {
         double* zp = A.warm_z + (size_t)inst * A.n_max;        // kept for the next solve of this instance
         for (int t = lane; t < L.n; t += NT) zp[t] = S.x[t];
     }
     // ---- certificate output (obca_set_certificate_buffers): primal vector and multipliers in objective units
+    if (!keep) { A.cert_z = nullptr; A.cert_y = nullptr; }
     if (A.cert_z != nullptr) {
         double* zc = A.cert_z + (size_t)inst * A.n_max;
         for (int t = lane; t < L.n; t += NT) zc[t] = S.x[t];
@@ -2402,18 +2530,21 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         const int N1 = L.N + 1;
         double* xo = A.xopt + (size_t)inst * 3 * N1;
         double* uo = A.uopt + (size_t)inst * 2 * L.N;
-        for (int t = lane; t < 3 * N1; t += NT) { const int j = t / N1, k = t - j * N1; xo[t] = S.x[L.ip(k) + j]; }
-        for (int t = lane; t < 2 * L.N; t += NT) { const int j = t / L.N, k = t - j * L.N; uo[t] = S.x[L.iu(k) + j]; }
+        if (keep) {
+            for (int t = lane; t < 3 * N1; t += NT) { const int j = t / N1, k = t - j * N1; xo[t] = S.x[L.ip(k) + j]; }
+            for (int t = lane; t < 2 * L.N; t += NT) { const int j = t / L.N, k = t - j * L.N; uo[t] = S.x[L.iu(k) + j]; }
+        }
         if (lane == 0) {
-            A.ts_opt[inst] = L.free_T ? S.x[L.iT()] * in.Ts : in.Ts;
-            A.status[inst] = status;
+            if (keep) A.ts_opt[inst] = L.free_T ? S.x[L.iT()] * in.Ts : in.Ts;
+            if (status_out != -100) A.status[inst] = status_out;
             // (counts of the whole sequence of passes; accumulated in LDS so that the pass number is dead after the prologue)
             const int itot = it + ladder_state[1], ftot = nfact + ladder_state[2];
             ladder_state[1] = itot; ladder_state[2] = ftot;
             A.iters[inst] = itot;
             if (A.info) {
                 double* io = A.info + (size_t)inst * 4;
-                io[0] = GET(IV_F) / sf; io[1] = GET(IV_EMAX); io[2] = GET(IV_E0); io[3] = (double)ftot;
+                if (keep) { io[0] = GET(IV_F) / sf; io[1] = GET(IV_EMAX); io[2] = GET(IV_E0); }
+                io[3] = (double)ftot;
             }
         }
     }

@@ -1524,6 +1524,28 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     const double dis = (S.xref[0 * N1 + L.N] - in.x0[0]) + (S.xref[1 * N1 + L.N] - in.x0[1]);
     in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
     const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
+    // obca_mpc6 whose terminal set no trajectory can reach (csrc/obca_device.h: obca_terminal_shortfall) is not run
+    if (L.variant == 6 && A.prm.opt.screen) {
+        const double sh = obca_terminal_shortfall(L.N, in.Ts, in.x0, in.u0[0], in.uL[0], in.uU[0], in.xU[0], in.term[0], A.prm.opt.feas_tol);
+        if (sh > 0.0) {
+            double* xo = A.xopt + inst * 3 * N1;
+            double* uo = A.uopt + inst * 2 * L.N;
+            for (int j = 0; j < 3; ++j) for (int k = 0; k < N1; ++k) xo[j * N1 + k] = in.x0[j];
+            for (int t = 0; t < 2 * L.N; ++t) uo[t] = 0.0;
+            A.ts_opt[inst] = in.Ts; A.status[inst] = OBCA_STATUS_INFEASIBLE; A.iters[inst] = 0;
+            if (A.info) { double* io = A.info + inst * 4; io[0] = 0.0; io[1] = sh; io[2] = 0.0; io[3] = 0.0; }
+            if (A.cert_z != nullptr) {
+                double* zc = A.cert_z + inst * (size_t)A.n_max;
+                for (int t = 0; t < L.n; ++t) zc[t] = 0.0;
+                for (int k = 0; k < N1; ++k) for (int j = 0; j < 3; ++j) zc[L.ip(k) + j] = in.x0[j];
+            }
+            if (A.cert_y != nullptr) {
+                double* yc = A.cert_y + inst * (size_t)(A.R_max + 2 * L.npair);
+                for (int q = 0; q < L.R + 2 * L.npair; ++q) yc[q] = 0.0;
+            }
+            return;
+        }
+    }
     // The start ladder (oracle/ipm_dense.py:solve; csrc/obca_kernel.hip runs the same passes): the starts of the order one after
     // the other until one ends at a feasible point; a free-time solve that converged with elastic variables left is first
     // repeated from the same start with rho x 100, then rho x 1000 (OBCA_RHO_ESCALATION; the next start begins at the base penalty again).  The caller's

@@ -24,6 +24,10 @@ class obca:
         # True: every call runs the first start of the order only.  A driver that answers a failed obca_mpc6 with obca_mpc8
         # itself (this package's closedLoop) asks for that per call instead: obca_mpc6(..., single_start=True).
         self.single_start = False
+        # include/obca_mpc.h: the ladder's last rung for obca_mpc6 / 8 (the window moved to either side, the better answer stays);
+        # the closed-form terminal-set screen of obca_mpc6 (a call that cannot succeed is answered feas=False without a solve)
+        self.dodge = True
+        self.terminal_screen = True
 
     def _solver(self, N, m):
         key = (int(N), tuple(m))
@@ -41,7 +45,7 @@ class obca:
         m, x0v, u0v, xr, A, b, Tsv, term = pack_reference_call(variant, Ts, N, x0, xref, nObs, vObs, AObs, bObs, u0,
                                                                 terminal_set)
         kw = dict(xL=xL, xU=xU, uL=uL, uU=uU, ego=ego, dmin=dmin)
-        kw.update(start_order=self.start_order, single_start=bool(single_start or self.single_start))
+        kw.update(start_order=self.start_order, single_start=bool(single_start or self.single_start), dodge=self.dodge, terminal_screen=self.terminal_screen)
         if variant == 4:
             prm = SolverParams(Q_free=Q, R_free=R, P_free=P, **kw)
         else:

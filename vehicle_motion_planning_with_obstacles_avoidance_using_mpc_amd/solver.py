@@ -35,7 +35,7 @@ class SolverParams:
                  ego=DEFAULT_EGO, dmin=0.05,
                  Q_free=None, R_free=None, P_free=None, Q_fix=None, R_fix=None, P_fix=None,
                  tol=0.0, rho=0.0, feas_tol=0.0, max_iter_free=0, max_iter_fixed=0, max_soc=0,
-                 start_order=0, single_start=False, patience=0, retry_iter=0):
+                 start_order=0, single_start=False, patience=0, retry_iter=0, dodge=True, terminal_screen=True):
         self.xL, self.xU, self.uL, self.uU = [tuple(float(v) for v in a[:2]) for a in (xL, xU, uL, uU)]
         self.ego = tuple(float(v) for v in ego)
         self.dmin = float(dmin)
@@ -49,11 +49,15 @@ class SolverParams:
         self.tol, self.rho, self.feas_tol = float(tol), float(rho), float(feas_tol)
         self.max_iter_free, self.max_iter_fixed = int(max_iter_free), int(max_iter_fixed)
         self.max_soc = int(max_soc)            # 0 = IPOPT's default (4), negative = no second-order correction
-        # the start ladder (include/obca_mpc.h): order "x0" (default: x0 -> window -> zeros) | "window" | "zeros" or the
-        # OBCA_START_* value; single_start: the first start only; patience / retry_iter: 0 = the defaults 500 + 10 N / 300 + 10 N
+        # the start ladder (include/obca_mpc.h): start_order "default" (obca_mpc4: x0 -> window -> zeros; obca_mpc6 / obca_mpc8: window -> x0
+        # -> zeros; x0 first also for a single start and for warm starts) | "x0" | "window" | "zeros" (that start first for every
+        # variant) or the OBCA_START_* value; single_start: the first start only; patience / retry_iter: 0 = the defaults
+        # 500 + 10 N / 300 + 10 N; dodge: the ladder's last rung for obca_mpc6 / 8 (the window moved to either side); terminal_screen:
+        # obca_mpc6 whose terminal set cannot be reached is answered without a solve
         self.start_order = int(_lib.START_ORDERS.get(start_order, start_order))
         self.single_start = bool(single_start)
         self.patience, self.retry_iter = int(patience), int(retry_iter)
+        self.dodge, self.terminal_screen = bool(dodge), bool(terminal_screen)
 
     def to_c(self):
         p = _lib.ObcaParams()
@@ -71,6 +75,7 @@ class SolverParams:
         p.max_soc = self.max_soc
         p.start_order, p.single_start = self.start_order, int(self.single_start)
         p.patience, p.retry_iter = self.patience, self.retry_iter
+        p.dodge, p.terminal_screen = (0 if self.dodge else -1), (0 if self.terminal_screen else -1)
         return p
 
 
