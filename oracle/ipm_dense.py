@@ -138,6 +138,7 @@ ORDER_NAMES = {"default": 0, "x0": 3, "window": 1, "zeros": 2}
 KIND_DODGE_R, KIND_DODGE_L = 3, 4
 DODGE_OFFSET = 3.0
 DODGE_RAMP = 3
+DODGE_MIN_SPARE = 0.1          # obca_mpc6: metres of reach beyond the terminal set below which the rung is not tried (OBCA_DODGE_MIN_SPARE)
 
 
 def retry_iter(N):
@@ -322,10 +323,9 @@ def solve(p, opts=None, trace=None):
     ``no_escalation``.  With ``single_start`` a pass runs to ``max_iter``; otherwise the first start's passes stop after
     ``patience`` iterations, the later starts' after ``retry_iter``."""
     opts = dict(opts or {})
-    if p.variant == 6 and opts.get("terminal_screen", True):
-        short = terminal_set_shortfall(p, opts.get("feas_tol"))
-        if short > 0.0:
-            return _screened(p, short)
+    short = terminal_set_shortfall(p, opts.get("feas_tol"))          # -inf unless obca_mpc6
+    if short > 0.0 and opts.get("terminal_screen", True):
+        return _screened(p, short)
     order = opts.get("start_order", 0)
     order = ORDER_NAMES.get(order, order)
     if order == 0:                 # the default: x0 first for the free-time problem, the window first for the fixed-time ones
@@ -360,7 +360,10 @@ def solve(p, opts=None, trace=None):
     r.restarted = r.starts_used > 1
     # the dodge rung: fixed-time problems only, after the order is exhausted; both sides run, the feasible answer with the lower
     # objective stays (a failed rung leaves the answer of the order's last pass, with the iterations added)
-    if p.variant != 4 and opts.get("dodge", True) and r.status not in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS):
+    # (obca_mpc6: only with room to dodge -- a detour of lateral offset d over a path of length L is about 2 d^2 / L longer, and
+    # with less than DODGE_MIN_SPARE of reach beyond the terminal set no offset that clears anything fits: the closed loop's
+    # terminal set x0 + 5 m is 1e-9 m inside the reach while the car runs straight at full speed)
+    if p.variant != 4 and opts.get("dodge", True) and short < -DODGE_MIN_SPARE and r.status not in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS):
         best = None
         it, nf = r.iters, getattr(r, "nfact", 0)
         for kind in (KIND_DODGE_R, KIND_DODGE_L):

@@ -366,6 +366,7 @@ typedef struct {
 enum { KIND_X0 = 0, KIND_WINDOW = 1, KIND_ZEROS = 2, KIND_DODGE_R = 3, KIND_DODGE_L = 4 };   /* the last two: oracle/ipm_dense.py:dodge_start */
 #define DODGE_OFFSET 3.0          /* csrc/obca_device.h: OBCA_DODGE_OFFSET */
 #define DODGE_RAMP 3
+#define DODGE_MIN_SPARE 0.1       /* csrc/obca_device.h: OBCA_DODGE_MIN_SPARE */
 /* index: the EFFECTIVE order 1, 2, 3 (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER; 0 = default: 3 for obca_mpc4, 1 for obca_mpc6 / 8) */
 static const int START_ORDERS[4][3] = {{KIND_X0, KIND_WINDOW, KIND_ZEROS}, {KIND_WINDOW, KIND_X0, KIND_ZEROS}, {KIND_ZEROS, KIND_WINDOW, KIND_X0}, {KIND_X0, KIND_WINDOW, KIND_ZEROS}};
 #define KAPPA_MU 0.2
@@ -936,7 +937,8 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         int it_sum = 0;
         double nf_sum = 0.0;
         status[q] = ST_MAXITER;
-        if (p.variant == 6 && prm->terminal_screen >= 0) {        /* oracle/ipm_dense.py:terminal_set_shortfall */
+        double shortfall = -INF;                                  /* oracle/ipm_dense.py:terminal_set_shortfall (-inf unless obca_mpc6) */
+        if (p.variant == 6) {
             double vhi = p.u0[0], vlo = p.u0[0], reach = 0.0;
             const double c0 = cos(p.x0[2]);
             for (int k = 0; k < N; ++k) {
@@ -946,7 +948,8 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
             }
             const double xN = fmin(p.x0[0] + reach, p.xU[0]);
             const double sh = p.term[0] - xN - 2.0 * o.feas_tol * (N + 2 + N * p.Ts + p.Ts * p.Ts * N * (N + 1) / 2.0);
-            if (sh > 0.0) {
+            shortfall = sh;
+            if (sh > 0.0 && prm->terminal_screen >= 0) {
                 for (int j = 0; j < 3; ++j) for (int k = 0; k <= N; ++k) xo[j * (N + 1) + k] = p.x0[j];
                 for (int t = 0; t < 2 * N; ++t) uo[t] = 0.0;
                 ts_opt[q] = p.Ts; status[q] = ST_INFEASIBLE; iters[q] = 0;
@@ -971,7 +974,7 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
         }
         /* the dodge rung (oracle/ipm_dense.py:solve): fixed-time problems after the order is exhausted; both sides run, the
            feasible answer with the lower objective stays */
-        if (p.variant != 4 && prm->dodge >= 0 && !(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
+        if (p.variant != 4 && prm->dodge >= 0 && shortfall < -DODGE_MIN_SPARE && !(status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) {
             double* xt_ = (double*)malloc(sizeof(double) * (3 * (N + 1) + 2 * N));
             double* ut_ = xt_ + 3 * (N + 1);
             int have = 0;

@@ -5,9 +5,9 @@ cumulative step lengths CasADi/IPOPT returned, as in the demo9 GIF).
 
 * Figure 12: demo1 of src/demo_setting.py (corridor 39 x 10, box 10..15 x 1..5, one 3 x 3 obstacle moving up at x = 22.5 with
   0.2 m/s), the closed loop as checked in (closed_loop_mpc4: N_free = N_fix = 6, senseDis = 10).
-* Figure 11: a corridor of 80 x 10 with two 3 x 3 obstacles that is NOT among the checked-in settings; reconstructed from the
-  frames: demo8's walls and obstacle pair (one moving up, one down, 0.1 m/s) at x = 30.5 and x = 39.5, start (3, 4), goal
-  (77, 4).
+* Figure 11: demo11 of src/demo_setting.py:248-269 (corridor 80 x 10, start (3, 4, 0), goal (77, 4, 0), two 3 x 3 obstacles: one
+  moving up at x = 30.5, one moving down at x = 39.5, 0.1 m/s), the closed loop as checked in.  The same run is recorded in
+  images/OBCA_dynObs_demo11.gif (tests/golden/make_gif_demo11_fixture.py reads its markers).
 
 The titles are four-digit numbers in raster images embedded in the PDF; they are TRANSCRIBED BY EYE (listed below) and
 cross-checked by this script against something it measures itself: the drawn position of the moving obstacle, which the
@@ -83,7 +83,7 @@ def main():
     ims = pdf_images()
     doc = {"source": "ME231_Team9_Project_Technical_Report.pdf of the reference repository, Figures 11 and 12 (frames of its closed loop)",
            "titles": "transcribed by eye; cross-check: drawn position of the moving obstacle = y0 + v * title"}
-    for name, F in (("figure12_demo1", FIG12), ("figure11_corridor", FIG11)):
+    for name, F in (("figure12_demo1", FIG12), ("figure11_demo11", FIG11)):
         frames = []
         for o, t in zip(F["objs"], F["titles"]):
             yc = box_centre_y(ims[o], F["xlim"], F["box_x"], F["thr"])
@@ -92,10 +92,7 @@ def main():
             print(name, o, t, "box centre y measured", frames[-1]["moving_box_centre_y_measured"], "from the title", frames[-1]["moving_box_centre_y_from_title"])
         doc[name] = {"frames": frames}
     doc["figure12_demo1"]["setting"] = "problemSetting('demo1'), closedLoop defaults as checked in (N_free = N_fix = 6, senseDis = 10), no stop at k = 30"
-    doc["figure11_corridor"]["setting"] = {"reconstructed": True, "xU": [79, 10], "start": [3, 4, 0], "goal": [77, 4, 0],
-                                           "walls": "as demo8 (y = 1 and y = 9)", "dyn": [[30.5, 0, "pi/2", 3, 3, 0.1, 30.5, 9, "pi/2", 0, 100],
-                                                                                        [39.5, 9, "-pi/2", 3, 3, 0.1, 39.5, 0, "-pi/2", 0, 200]],
-                                           "terminal_set": [[25, 79], [2, 6]]}
+    doc["figure11_demo11"]["setting"] = "problemSetting('demo11') (src/demo_setting.py:248-269), closedLoop defaults as checked in (N_free = N_fix = 6, senseDis = 10), no stop at k = 30"
     with open(os.path.join(HERE, "reference_report_figures.json"), "w") as f:
         json.dump(doc, f, indent=1)
 

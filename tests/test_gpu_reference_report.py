@@ -18,11 +18,3 @@ def test_product_path_shows_the_four_titles_of_figure_12():
     hits = reference_report.match(cum, sorted(f["spend_time"] for f in fx["figure12_demo1"]["frames"]))
     assert [k for k, _ in hits] == [5, 14, 19, 29]
     assert max(e for _, e in hits) <= reference_report.TIME_TOL, hits
-
-
-def test_product_path_shows_the_titles_of_the_reconstructed_figure_11():
-    fx = reference_report.fixture()
-    cum, cl = reference_report.replay(reference_report.corridor_setting(fx), _solver(), 41)
-    hits = reference_report.match(cum, sorted(f["spend_time"] for f in fx["figure11_corridor"]["frames"]))
-    assert [k for k, _ in hits[:3]] == [23, 29, 39]
-    assert max(e for _, e in hits[:3]) <= reference_report.TIME_TOL, hits

@@ -2,9 +2,8 @@
 tests/golden/reference_report_figures.json): every frame title is ``sum(Ts_opt[:k])`` of a run CasADi/IPOPT solved.
 
 Figure 12 is demo1 with the closed loop as checked in -- 7 x obca_mpc4, then obca_mpc6 against the sensed moving box: the four
-titles are the cumulative times after steps 5, 14, 19 and 29 of this build's run.  Figure 11 is a corridor that is not among the
-checked-in settings (reconstructed from the frames): the three titles of its first 39 steps are met; the last frame (98.55 s,
-after the second obstacle) lies between two steps of this build's run, 0.7 s from either -- reported, not asserted."""
+titles are the cumulative times after steps 5, 14, 19 and 29 of this build's run.  Figure 11 is demo11 as checked in
+(src/demo_setting.py:248-269): tests/test_reference_demo11.py."""
 import numpy as np
 import pytest
 
@@ -19,7 +18,7 @@ def fx():
 def test_fixture_cross_check(fx):
     """where the script could measure the moving obstacle's drawn position it agrees with speed x title to 0.06 m (0.3-0.6 s)"""
     n = 0
-    for fig in ("figure12_demo1", "figure11_corridor"):
+    for fig in ("figure12_demo1", "figure11_demo11"):
         for f in fx[fig]["frames"]:
             if f["moving_box_centre_y_measured"] is not None:
                 assert abs(f["moving_box_centre_y_measured"] - f["moving_box_centre_y_from_title"]) <= 0.06
@@ -37,12 +36,3 @@ def test_demo1_run_shows_the_four_titles_of_figure_12(fx, engine):
     assert max(e for _, e in hits) <= reference_report.TIME_TOL, hits
     got = [c["variant"] for c in s.calls[:29]]
     assert got[:7] == [4] * 7 and set(got[7:]) <= {6, 8} and all(c["status"] in (0, 1) for c in s.calls[:29] if c["variant"] != 6)
-
-
-def test_reconstructed_corridor_run_shows_the_titles_of_figure_11(fx):
-    s = native_build.LpiObca()
-    cum, cl = reference_report.replay(reference_report.corridor_setting(fx), s, 64)
-    titles = sorted(f["spend_time"] for f in fx["figure11_corridor"]["frames"])
-    hits = reference_report.match(cum, titles)
-    assert [k for k, _ in hits[:3]] == [23, 29, 39]
-    assert max(e for _, e in hits[:3]) <= reference_report.TIME_TOL, hits

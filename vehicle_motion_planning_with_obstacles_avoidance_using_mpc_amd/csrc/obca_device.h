@@ -73,6 +73,10 @@
 #define OBCA_KIND_DODGE_L 4
 #define OBCA_DODGE_OFFSET 3.0
 #define OBCA_DODGE_RAMP 3
+/* obca_mpc6: the rung is tried only with at least this much reach beyond the terminal set (metres; obca_terminal_shortfall < -this): a
+   detour of lateral offset d over a path of length L is about 2 d^2 / L longer, so below it no offset that clears anything fits -- and the
+   closed loop's terminal set (x0 + 5 m, five steps of exactly 1 m) has 1e-9 m to spare while the car runs straight at full speed */
+#define OBCA_DODGE_MIN_SPARE 0.1
 /* transient, kernel-internal: a feasible answer of the first dodge pass waiting for the second one (never returned to a caller) */
 #define OBCA_STATUS_DODGE_OK 3
 #define OBCA_STATUS_DODGE_ACC 4
@@ -196,15 +200,14 @@ static inline bool obca_resolve_starts(ObcaOptsDev* o, int start_order, int sing
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-static inline double obca_terminal_shortfall(int N, double Ts, const double* x0, double u0v, double uL0, double uU0, double xU0, double termx, double feas_tol) {
+static inline double obca_terminal_shortfall(int N, double Ts, double x0x, double c0 /* cos of x0's heading */, double u0v, double uL0, double uU0, double xU0, double termx, double feas_tol) {
     double vhi = u0v, vlo = u0v, reach = 0.0;
-    const double c0 = cos(x0[2]);
     for (int k = 0; k < N; ++k) {
         vhi = fmin(uU0, vhi + OBCA_ACC_MAX0 * Ts);
         vlo = fmax(uL0, vlo - OBCA_ACC_MAX0 * Ts);
         reach += Ts * (k == 0 ? fmax(vhi * c0, vlo * c0) : fmax(fabs(vhi), fabs(vlo)));
     }
-    const double xN = fmin(x0[0] + reach, xU0);
+    const double xN = fmin(x0x + reach, xU0);
     const double margin = 2.0 * feas_tol * (N + 2 + N * Ts + Ts * Ts * N * (N + 1) / 2.0);
     return termx - xN - margin;
 }

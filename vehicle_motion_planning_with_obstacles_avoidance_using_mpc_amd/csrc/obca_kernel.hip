@@ -1722,40 +1722,6 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     __shared__ int ladder_state[4];      // [0] escalation level of the current start (0: base penalty), [1] iterations, [2] factorisations so far, [3] index of the current start (nstarts, nstarts + 1: the dodge passes)
     __shared__ double ladder_f;          // objective of a feasible first dodge pass
     const int order = OBCA_EFFECTIVE_ORDER(Ain.prm.opt.order, A.variant[inst], A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0), Ain.prm.opt.nstarts == 1);
-    // obca_mpc6 whose terminal set no trajectory can reach (csrc/obca_device.h: obca_terminal_shortfall) is not run: status
-    // 'infeasible', zero iterations, the x0 start as the iterate.  Checked at the head of every pass (a handful of scalar
-    // operations), so that the ladder does not climb on it either.
-    if (A.variant[inst] == 6 && Ain.prm.opt.screen) {
-        double x0s[3];
-        for (int j = 0; j < 3; ++j) x0s[j] = A.x0[(size_t)inst * 3 + j];
-        const double ts = A.Ts[inst];
-        const double sh = obca_terminal_shortfall(A.N, ts, x0s, A.u0[(size_t)inst * 2], Ain.prm.uL[0], Ain.prm.uU[0], Ain.prm.xU[0],
-                                                  A.term[(size_t)inst * 3], Ain.prm.opt.feas_tol);
-        if (sh > 0.0) {
-            if (first) {
-                const int N1 = A.N + 1;
-                double* xo = A.xopt + (size_t)inst * 3 * N1;
-                double* uo = A.uopt + (size_t)inst * 2 * A.N;
-                for (int t = lane; t < 3 * N1; t += NT) xo[t] = x0s[t / N1];
-                for (int t = lane; t < 2 * A.N; t += NT) uo[t] = 0.0;
-                if (A.cert_z != nullptr) {
-                    double* zc = A.cert_z + (size_t)inst * A.n_max;
-                    const int NSs = 5 + A.M + 4 * A.nO, nn = N1 * (3 + A.M + 4 * A.nO) + 2 * A.N;
-                    for (int t = lane; t < nn; t += NT) { const int k = t / NSs, q = t - k * NSs; zc[t] = q < 3 ? x0s[q] : 0.0; }
-                }
-                if (A.cert_y != nullptr) {
-                    double* yc = A.cert_y + (size_t)inst * (A.R_max + 2 * N1 * A.nO);
-                    const int Rv = 3 + 3 * A.N + 2 * N1 + 4 * A.N + 2 + N1 * (2 * A.nO + A.M + 4 * A.nO);      // rows of obca_mpc6
-                    for (int t = lane; t < Rv + 2 * N1 * A.nO; t += NT) yc[t] = 0.0;
-                }
-                if (lane == 0) {
-                    A.ts_opt[inst] = ts; A.status[inst] = OBCA_STATUS_INFEASIBLE; A.iters[inst] = 0;
-                    if (A.info) { double* io = A.info + (size_t)inst * 4; io[0] = 0.0; io[1] = sh; io[2] = 0.0; io[3] = 0.0; }
-                }
-            }
-            return;
-        }
-    }
     int start_s = 0, escalated = 0;
     if (!first) {
         const int st0 = __builtin_amdgcn_readfirstlane(A.status[inst]);     // wave-uniform: the flags below stay scalar
@@ -2550,6 +2516,41 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     }
 }
 
+// The closed-form terminal-set screen of obca_mpc6 (csrc/obca_device.h: obca_terminal_shortfall; rule: oracle/ipm_dense.py:
+// terminal_set_shortfall), run by the pass drivers BEFORE the first pass of an instance: a call whose terminal set no trajectory can
+// reach is answered here -- status 'infeasible', zero iterations, the x0 start as the iterate -- and the solver body is not
+// entered.  Out of line and outside the body on purpose: inside the body's prologue the same forty lines cost the headline kernel
+// 85 more scratch loads (the allocator's choices for the whole solve changed).  // Returns 1: screened out; 2: not screened, but with less than OBCA_DODGE_MIN_SPARE of reach beyond the terminal set -- the ladder's
+// dodge rung is not tried (the drivers stop after the order's starts); 0: nothing to say.
+__device__ __noinline__ int terminal_screen_dev(const ObcaLaunch* a, int inst, int lane, int nt) {
+    if (inst >= a->B || a->term == nullptr || a->variant[inst] != 6) return 0;
+    const double* x0s = a->x0 + (size_t)inst * 3;
+    const double ts = a->Ts[inst];
+    const double sh = obca_terminal_shortfall(a->N, ts, x0s[0], cos(x0s[2]), a->u0[(size_t)inst * 2], a->prm.uL[0], a->prm.uU[0], a->prm.xU[0],
+                                              a->term[(size_t)inst * 3], a->prm.opt.feas_tol);
+    if (!(sh > 0.0 && a->prm.opt.screen)) return (a->prm.opt.dodge && !(sh < -OBCA_DODGE_MIN_SPARE)) ? 2 : 0;
+    const int N1 = a->N + 1;
+    double* xo = a->xopt + (size_t)inst * 3 * N1;
+    double* uo = a->uopt + (size_t)inst * 2 * a->N;
+    for (int t = lane; t < 3 * N1; t += nt) xo[t] = x0s[t / N1];
+    for (int t = lane; t < 2 * a->N; t += nt) uo[t] = 0.0;
+    if (a->cert_z != nullptr) {
+        double* zc = a->cert_z + (size_t)inst * a->n_max;
+        const int NSs = 5 + a->M + 4 * a->nO, nn = N1 * (3 + a->M + 4 * a->nO) + 2 * a->N;
+        for (int t = lane; t < nn; t += nt) { const int k = t / NSs, q = t - k * NSs; zc[t] = q < 3 ? x0s[q] : 0.0; }
+    }
+    if (a->cert_y != nullptr) {
+        double* yc = a->cert_y + (size_t)inst * (a->R_max + 2 * N1 * a->nO);
+        const int Rv = 3 + 3 * a->N + 2 * N1 + 4 * a->N + 2 + N1 * (2 * a->nO + a->M + 4 * a->nO);      // rows of obca_mpc6
+        for (int t = lane; t < Rv + 2 * N1 * a->nO; t += nt) yc[t] = 0.0;
+    }
+    if (lane == 0) {
+        a->ts_opt[inst] = ts; a->status[inst] = OBCA_STATUS_INFEASIBLE; a->iters[inst] = 0;
+        if (a->info) { double* io = a->info + (size_t)inst * 4; io[0] = 0.0; io[1] = sh; io[2] = 0.0; io[3] = 0.0; }
+    }
+    return 1;
+}
+
 // rows per lane: 4 covers R <= 256 (N=5/6 with 3 obstacles), 6 covers R <= 384 (demo9, 4-5 obstacles)
 // The solve and, for the instances that need them, the further passes of the start ladder (penalty escalation, next starts).
 // Two forms, chosen per kernel by measurement (tools/build_variant.sh, tools/gpu_variant_bench.py, tools/kernel_resources.py):
@@ -2566,6 +2567,13 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
 template <int RPL, bool LOOP, class DESC, class SHAPE = ShapeAny>
 __device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
     const int inst = blockIdx.x;
+    // (every kernel's first argument is the launch descriptor: its address is the kernarg segment's)
+    __shared__ int drv_scr;           // what the screen said (kept in LDS: nothing of it may occupy a register during the solves)
+    {
+        const int scr = terminal_screen_dev((const ObcaLaunch*)__builtin_amdgcn_kernarg_segment_ptr(), inst, threadIdx.x, blockDim.x);
+        if (scr == 1) return;
+        if (threadIdx.x == 0) drv_scr = scr;
+    }
     if constexpr (LOOP) {
         if (inst >= A.B) return;
 #pragma clang loop unroll(disable)
@@ -2574,6 +2582,7 @@ __device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
             __syncthreads();                                        // status written by thread 0 of this workgroup
             const int st = A.status[inst];
             if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing (more) to recover
+            if (drv_scr == 2 && pass + 1 == A.prm.opt.nstarts) return;       // obca_mpc6 without room to dodge: the order's starts were all
         }
     } else {
         static_assert(OBCA_MAX_PASSES == 9, "one inlined copy of the body per pass");
@@ -2584,10 +2593,12 @@ __device__ __forceinline__ void solve_passes(DESC& A, DESC& A2, DESC& A3) {
             const int st = A2.status[inst];
             if (st == OBCA_STATUS_OK || st == OBCA_STATUS_ACCEPTABLE || st < OBCA_STATUS_NUMERIC) return;   // nothing to recover
         }
+        if (drv_scr == 2 && A2.prm.opt.nstarts == 1) return;        // obca_mpc6 without room to dodge: the order's starts were all
         obca_ipm_body<RPL, false, DESC, SHAPE>(A2, inst, false);
         __syncthreads();
         obca_ipm_body<RPL, false, DESC, SHAPE>(A3, inst, false);
         __syncthreads();
+        if (drv_scr == 2 && A3.prm.opt.nstarts == 3) return;
         obca_ipm_body<RPL, false, DESC, SHAPE>(A2, inst, false);
         __syncthreads();
         obca_ipm_body<RPL, false, DESC, SHAPE>(A3, inst, false);
@@ -2651,6 +2662,7 @@ extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A
 // its vertex arrays) is hoisted out of the step loop and kept alive in registers across the solve.
 __device__ __noinline__ void ro_prepare(const rollout::Dev* D, int b) { rollout::prepare(*D, b); }
 __device__ __noinline__ void ro_finish(const rollout::Dev* D, int b) { rollout::finish(*D, b); }
+__device__ __noinline__ int ro_screen(const ObcaLaunch* L, int b) { return terminal_screen_dev(L, b, 0, 1); }
 __device__ __noinline__ int ro_retry(const rollout::Dev* D, int g, int b) { rollout::make_retry(*D, g, b); return D->var8[g][b]; }
 // (flag in the low half, group in the high half: an out-parameter would be a stack slot, i.e. scratch)
 __device__ __noinline__ long long ro_flag_sel(const rollout::Dev* D, int b) { return ((long long)D->sel[b] << 32) | (unsigned)D->flags[b]; }
@@ -2684,6 +2696,7 @@ __device__ __noinline__ long long ro_flag_sel(const rollout::Dev* D, int b) { re
 template <int RPL, class SHAPE>
 __device__ __forceinline__ void ro_solve_step(const rollout::Dev& D, const ObcaLaunch* launches, const int g, const int b, int* ro_msg) {
     const int lane = threadIdx.x;
+    bool nodge = false;
     for (int attempt = 0; attempt < 2 * OBCA_MAX_PASSES; ++attempt) {
         const ObcaLaunch* Lp = launches + g;
         if (attempt >= OBCA_MAX_PASSES) {
@@ -2697,6 +2710,15 @@ __device__ __forceinline__ void ro_solve_step(const rollout::Dev& D, const ObcaL
             }
             Lp = launches + g + rollout::MAX_GROUPS;
         }
+        if (attempt == 0 && g > 0) {      // obca_mpc6 that cannot reach its terminal set: answered by lane 0, on to obca_mpc8's turn
+            if (lane == 0) ro_msg[0] = ro_screen(Lp, b);
+            __syncthreads();
+            const int scr = ro_msg[0];
+            __syncthreads();
+            if (scr == 1) { attempt = OBCA_MAX_PASSES - 1; continue; }
+            nodge = scr == 2;
+        }
+        if (nodge && attempt == Lp->prm.opt.nstarts) { attempt = OBCA_MAX_PASSES - 1; continue; }     // ... without room to dodge: no rung
         obca_ipm_body<RPL, false, ObcaLaunchConst, SHAPE>(*(ObcaLaunchConst*)Lp, b, attempt == 0 || attempt == OBCA_MAX_PASSES);
         __syncthreads();
         {   // nothing (more) to recover: on to obca_mpc8's turn, or out

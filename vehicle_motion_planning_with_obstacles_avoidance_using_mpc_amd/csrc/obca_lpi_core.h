@@ -1525,9 +1525,11 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
     const bool warm = A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0);
     // obca_mpc6 whose terminal set no trajectory can reach (csrc/obca_device.h: obca_terminal_shortfall) is not run
-    if (L.variant == 6 && A.prm.opt.screen) {
-        const double sh = obca_terminal_shortfall(L.N, in.Ts, in.x0, in.u0[0], in.uL[0], in.uU[0], in.xU[0], in.term[0], A.prm.opt.feas_tol);
-        if (sh > 0.0) {
+    double shortfall = -INFINITY;
+    if (L.variant == 6) {
+        const double sh = obca_terminal_shortfall(L.N, in.Ts, in.x0[0], cos(in.x0[2]), in.u0[0], in.uL[0], in.uU[0], in.xU[0], in.term[0], A.prm.opt.feas_tol);
+        shortfall = sh;
+        if (sh > 0.0 && A.prm.opt.screen) {
             double* xo = A.xopt + inst * 3 * N1;
             double* uo = A.uopt + inst * 2 * L.N;
             for (int j = 0; j < 3; ++j) for (int k = 0; k < N1; ++k) xo[j * N1 + k] = in.x0[j];
@@ -1604,7 +1606,7 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     // The dodge rung (csrc/obca_device.h: OBCA_KIND_DODGE_*): fixed-time problems on which every start of the order ended
     // without a feasible point -- the window moved to the right, then to the left; both run, the feasible answer with the lower
     // objective is the one that stays in the caller's buffers (the first pass's outputs are overwritten only by a better one)
-    if (O0.dodge && !L.free_T && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
+    if (O0.dodge && !L.free_T && shortfall < -OBCA_DODGE_MIN_SPARE && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
         bool have = false;
         double fbest = 0.0;
         for (int side = 0; side < 2; ++side) {
