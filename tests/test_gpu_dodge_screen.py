@@ -75,9 +75,10 @@ def test_demo11_calls_kernels_equal_host_core_through_the_dodge_rung():
                 for k in dev:
                     assert np.array_equal(ref[key][k], dev[k]), k
     assert n_dodged >= 3
-    # without the rung the three calls come back infeasible, on the GPU as on the host
+    # without the rung those calls come back infeasible, on the GPU as on the host (two of the run's three with the default
+    # position box this test solves them in)
     off = _solve_all(calls, ("auto",), dodge=False)
-    assert all(np.array_equal(dev["status"], host["status"]) for _, host, dev in off) and sum(int((dev["status"] == 2).sum()) for _, _, dev in off) >= 3
+    assert all(np.array_equal(dev["status"], host["status"]) for _, host, dev in off) and sum(int((dev["status"] == 2).sum()) for _, _, dev in off) >= 2
 
 
 def test_c5_calls_screened_alike_and_identical_to_the_host_core():
