@@ -150,7 +150,7 @@ def cpu_baseline(batch, N):
 _C3_BATCHES = {}          # generated once per run (the start-order legs solve the same instances)
 
 
-def config_c3(B, N=20, start_order=0):
+def config_c3(B, N=20, start_order=0, classify=False):
     """Config C3: N=20, walls + box + two moving boxes, lidar-gated: the free-time sub-batch (obca_mpc4, three
     static obstacles) and the gated sub-batch (obca_mpc6, five obstacles, time-varying rows), B UNIQUE seeded instances
     each; both run on the four-wavefront LDS kernel."""
@@ -180,10 +180,23 @@ def config_c3(B, N=20, start_order=0):
                      "status_counts": {str(k): int((st == k).sum()) for k in np.unique(st)},
                      "mean_ipm_iters": float(out.iters.float().mean()), "lds_bytes": s.lds_bytes}
         s.close()
+        bad = np.flatnonzero(~np.isin(st, (0, 1)))
+        if classify and len(bad) and len(bad) <= 64:
+            # every instance the ladder gave up on: SciPy SLSQP on the pinned model from seven starts (tests/independent.py:classify)
+            try:
+                from tests import independent as ind, kkt_check
+                probs = [kkt_check.problem_of(b, int(i), N) for i in bad]
+                rows = ind.pool_map(ind.classify, [(q, ind.trajectory_start(q, q.xref), int(i)) for q, i in zip(probs, bad)], min(len(bad), os.cpu_count() or 1))
+                res[name]["failures_classified"] = {"instances": [int(i) for i in bad],
+                                                    "feasible_point_exists_solver_failure": [int(r["tag"]) for r in rows if r["feasible_point_found"]],
+                                                    "no_feasible_point_found": int(sum(not r["feasible_point_found"] for r in rows)),
+                                                    "method": "SciPy SLSQP on the pinned model, seven starts each (window, straight line, window moved 1.5 / 3 m to either side)"}
+            except Exception as e:          # noqa: BLE001
+                res[name]["failures_classified"] = {"error": repr(e)}
     return res
 
 
-def open_loop(cases=(("demo9", 10), ("demo9", 74), ("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="default"):
+def open_loop(cases=(("demo9", 10), ("demo9", 74), ("demo1", 10), ("demo1", 74), ("demo9", 66)), start_order="default", classify=False):
     """Row N3: the reference's open-loop free-time plan (closedLoop.mpc_openLoop_freeTime, src/closed_loop.py:113-120) as ONE
     instance through the drop-in `obca` class -- the only timing the reference publishes (src/simulation.py:210-231 calc_time,
     called for demo9 in main.py:28: N = 74 -- the length of demo9's A* route -- 136.69 s, N = 10 3.69 s, hardware unspecified; demo9
@@ -208,6 +221,26 @@ def open_loop(cases=(("demo9", 10), ("demo9", 74), ("demo1", 10), ("demo1", 74),
         dt = time.perf_counter() - t
         res["%s_N%d" % (demo, N)] = {"seconds": dt, "feas": bool(cl.feas), "ipm_iters": s.last["iters"], "status": s.last["status"],
                                      "Ts_opt": float(cl.Ts_opt), "reference_published_s": pub.get((demo, N))}
+        if not cl.feas and classify:
+            # reported infeasible: the same problem (captured from the host build of the core) to SciPy SLSQP, seven starts
+            try:
+                from oracle.obca_nlp import Problem
+                from tests import independent as ind, native_build
+                from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
+                cpu = native_build.LpiObca()
+                c2 = closedLoop(problemSetting(demo), solver=cpu)
+                c2.N_free = N
+                c2.mpc_openLoop_freeTime()
+                c = cpu.calls[-1]
+                sp = SolverParams(xL=c2.xL[:2], xU=c2.xU[:2])
+                q = Problem(4, N, c["m"], c["x0"], c["u0"], c["xref"], c["A"], c["b"], c["Ts"], sp.Q_free, sp.R_free[0], sp.R_free[1], sp.P_free,
+                            sp.xL, sp.xU, sp.uL, sp.uU, sp.ego, sp.dmin)
+                r = ind.classify((q, ind.trajectory_start(q, q.xref), "%s_N%d" % (demo, N)))
+                res["%s_N%d" % (demo, N)]["classified"] = {"feasible_point_found": r["feasible_point_found"], "smallest_violation": r["viol"], "from_start": r["start"],
+                                                          "max_Topt": float(q.Tmax), "host_core_status": c["status"],
+                                                          "method": "SciPy SLSQP on the pinned model, seven starts (tests/independent.py:classify)"}
+            except Exception as e:          # noqa: BLE001
+                res["%s_N%d" % (demo, N)]["classified"] = {"error": repr(e)}
     # the plan the reference repository shows in images/aStar_vs_openLoopOBCA.png (demo9, N = 50, Q = 0.5 I; fixture
     # tests/golden/reference_openloop_demo9.json): how far are the picture's dots from this build's poses?
     try:
@@ -231,18 +264,27 @@ def open_loop(cases=(("demo9", 10), ("demo9", 74), ("demo1", 10), ("demo1", 74),
 
 def report_figures_leg():
     """closed-loop frames of the reference's project report (tests/golden/reference_report_figures.json: titles = sum(Ts_opt[:k])
-    of runs IPOPT solved) replayed through the product path: how many titles does this build's run show?"""
+    of runs IPOPT solved) replayed through the product path: how many titles does this build's run show?  Figure 12 = demo1,
+    Figure 11 = demo11, both as checked in; the demo11 run is also recorded in images/OBCA_dynObs_demo11.gif, whose closed-loop
+    markers tests/golden/reference_gif_demo11.json holds."""
     from tests import reference_report
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.obca import obca
     fx = reference_report.fixture()
-    out = {"fixture": "tests/golden/reference_report_figures.json", "tolerance_s": reference_report.TIME_TOL}
-    for name, setting, n in (("figure12_demo1", reference_report.demo1_setting(), 31), ("figure11_corridor_reconstructed", reference_report.corridor_setting(fx), 64)):
+    out = {"fixture": "tests/golden/reference_report_figures.json, tests/golden/reference_gif_demo11.json", "tolerance_s": reference_report.TIME_TOL}
+    for name, setting, n in (("figure12_demo1", reference_report.demo1_setting(), 31), ("figure11_demo11", reference_report.demo11_setting(), 61)):
         t0 = time.perf_counter()
-        cum, _ = reference_report.replay(setting, obca(), n)
-        titles = sorted(f["spend_time"] for f in fx["figure11_corridor" if "11" in name else name]["frames"])
+        cum, cl = reference_report.replay(setting, obca(), n)
+        titles = sorted(f["spend_time"] for f in fx[name]["frames"])
         hits = reference_report.match(cum, titles)
         out[name] = {"titles": titles, "nearest_step": [k for k, _ in hits], "distance_s": [round(e, 4) for _, e in hits],
                      "titles_shown": int(sum(e <= reference_report.TIME_TOL for _, e in hits)), "steps_run": int(len(cum)), "seconds": time.perf_counter() - t0}
+        if name == "figure11_demo11":
+            g = reference_report.gif_demo11()
+            M, first = np.array(g["markers_xy"]), g["first_marker_is_pose"]
+            X = np.asarray(cl.x_closed)[first:first + len(M), :2]
+            d = np.hypot(*(X[:len(M)] - M[:len(X)]).T)
+            out[name].update({"gif_markers": int(len(M)), "marker_to_pose_max_m": float(d.max()), "marker_to_pose_mean_m": float(d.mean()),
+                              "marker_accuracy_m": 0.15, "fourth_title_tolerance_s": reference_report.DEMO11_FOURTH_TOL})
     return out
 
 
@@ -594,8 +636,8 @@ def main():
                       ("reference_report_figures", report_figures_leg),
                       ("window_first", window_first_all),
                       ("zeros_first", zeros_first),
-                      ("open_loop", open_loop),
-                      ("config_c3", lambda: config_c3(B)),
+                      ("open_loop", lambda: open_loop(classify=not args.no_cpu_baseline)),
+                      ("config_c3", lambda: config_c3(B, classify=not args.no_cpu_baseline)),
                       ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts, classify=not args.no_cpu_baseline,
                                                              classify_max=None if args.classify_all else 96)),
                       # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes

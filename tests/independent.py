@@ -7,8 +7,8 @@ IPOPT are not installed).  Used three ways:
   from_starts(p, z)   started from the reference window as a trajectory and from two perturbations of it: does an
                       independent method reach the SAME optimum, another one, a better one?  (SLSQP cannot start from the
                       reference's own all-zero point: "singular matrix C", SURVEY Appendix C.)
-  classify(p, z)      for an instance the product gave up on: any feasible point found => "solver failure", none => "no
-                      feasible point found" (likely genuinely infeasible; not a proof).
+  classify(p, z)      for an instance the product gave up on: any feasible point found (seven starts, four of them beside the
+                      window) => "solver failure", none => "no feasible point found" (likely genuinely infeasible; not a proof).
 Worker functions are module-level so that they can run in a process pool (spawn context: no HIP state is inherited)."""
 import numpy as np
 from scipy.optimize import minimize
@@ -137,11 +137,31 @@ def from_starts(job):
     return dict(f0=f0, starts=out)
 
 
+def lateral_points(p, d, ramp=3):
+    """the reference window moved sideways by d metres (ramped in over `ramp` stages), headings along the moved poses -- a start in
+    the basin of a plan AROUND what the window runs into (round 5: the window, the straight line and the solver's last iterate
+    are all symmetric about a head-on obstacle, and SLSQP from them called steps 21-25 of the reference's demo11 run infeasible,
+    which they are not)"""
+    base = p.xref.copy().astype(float)
+    base[:, 0] = p.x0
+    out = base.copy()
+    for k in range(1, p.N + 1):
+        a = base[:2, min(k + 1, p.N)] - base[:2, k - 1]
+        n = np.array([-a[1], a[0]]) / max(np.hypot(*a), 1e-9)
+        out[:2, k] = base[:2, k] + d * min(1.0, k / ramp) * n
+    for k in range(1, p.N):
+        dd = out[:2, k + 1] - out[:2, k]
+        out[2, k] = np.arctan2(dd[1], dd[0])
+    out[2, p.N] = out[2, p.N - 1]
+    return out
+
+
 def classify(job):
-    """job = (p, last iterate of the product, tag): a feasible point from the window, a straight line or the last iterate"""
+    """job = (p, last iterate of the product, tag): a feasible point from the window, a straight line, the last iterate, or the
+    window moved 1.5 / 3 m to either side"""
     p, z_last, tag = job
     best = None
-    for kind in ("window", "line", "last_iterate"):
+    for kind in ("window", "line", "last_iterate", "right 1.5", "left 1.5", "right 3", "left 3"):
         if kind == "window":
             z0 = trajectory_start(p, p.xref)
         elif kind == "line":
@@ -149,8 +169,11 @@ def classify(job):
             if p.variant == 6:
                 end[0] = max(end[0], p.term[0] + 0.1)
             z0 = trajectory_start(p, np.linspace(p.x0, end, p.N + 1).T)
-        else:
+        elif kind == "last_iterate":
             z0 = np.asarray(z_last, float)[:p.n].copy()
+        else:
+            side, d = kind.split()
+            z0 = trajectory_start(p, lateral_points(p, (-1.0 if side == "right" else 1.0) * float(d)))
         r = slsqp(p, z0, maxiter=250)
         cand = dict(start=kind, viol=r["viol"], f=r["f"], nit=r["nit"])
         if best is None or (cand["viol"] <= FEAS_TOL and (best["viol"] > FEAS_TOL or cand["f"] < best["f"])) or \
