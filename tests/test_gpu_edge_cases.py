@@ -33,6 +33,22 @@ def test_empty_batch_and_argument_errors():
     assert lib.obca_solve_batch(*args(5, p(d["x0"]))) == -22                    # beyond max_batch
     assert lib.obca_solve_batch(*args(-1, p(d["x0"]))) == -22
     assert lib.obca_solve_batch(*args(4, None)) == -22                          # NULL input
+    # obca_params.struct_size (obca_mpc 0.5): a struct that was never initialised, or one of another layout, is refused instead of
+    # being read field by field as something it is not; obca_params_init() leaves what a new ObcaParams() holds
+    good = cp.struct_size
+    assert good == ctypes.sizeof(_lib.ObcaParams)
+    for bad in (0, good - 8, good + 8):
+        cp.struct_size = bad
+        assert lib.obca_solve_batch(*args(4, p(d["x0"]))) == -22
+    cp.struct_size = good
+    assert lib.obca_solve_batch(*args(4, p(d["x0"]))) == 0
+    raw = _lib.ObcaParams()
+    ctypes.memset(ctypes.byref(raw), 0xff, ctypes.sizeof(raw))
+    lib.obca_params_init(ctypes.byref(raw))
+    assert raw.struct_size == good and bytes(raw)[4:] == bytes(ctypes.sizeof(raw) - 4)
+    for field, v in (("dodge", 7), ("terminal_screen", -3)):                   # any positive value: on, any negative: off
+        setattr(cp, field, v)
+        assert lib.obca_solve_batch(*args(4, p(d["x0"]))) == 0
     with pytest.raises(ValueError):
         s.solve(d["variant"], d["x0"][:, :2], d["u0"], d["xref"], d["A"], d["b"], d["Ts"], d["term"])
     assert lib.obca_set_mode(s._h, 7) == -22

@@ -161,6 +161,8 @@ def load():
     lib.obca_lds_bytes.restype = ctypes.c_int64
     lib.obca_strerror.argtypes = [ctypes.c_int]
     lib.obca_strerror.restype = ctypes.c_char_p
+    lib.obca_params_init.argtypes = [ctypes.POINTER(ObcaParams)]
+    lib.obca_params_init.restype = None
     lib.obca_version.argtypes = []
     lib.obca_version.restype = ctypes.c_char_p
     _lib = lib
