@@ -29,7 +29,7 @@ ALG_BYTES = {(5, 6): 1320, (5, 12): 2184, (6, 6): 1528}       # SURVEY.md 8(d): 
 HBM_PEAK_GBPS = 8000.0                                          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
 VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9        # lanes the VALUs of the chip issue per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12
 
 
