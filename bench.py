@@ -235,10 +235,10 @@ def open_loop(cases=(("demo9", 10), ("demo9", 74), ("demo1", 10), ("demo1", 74),
                 sp = SolverParams(xL=c2.xL[:2], xU=c2.xU[:2])
                 q = Problem(4, N, c["m"], c["x0"], c["u0"], c["xref"], c["A"], c["b"], c["Ts"], sp.Q_free, sp.R_free[0], sp.R_free[1], sp.P_free,
                             sp.xL, sp.xU, sp.uL, sp.uU, sp.ego, sp.dmin)
-                r = ind.classify((q, ind.trajectory_start(q, q.xref), "%s_N%d" % (demo, N)))
+                r = ind.classify((q, None, "%s_N%d" % (demo, N), ("window", "line", "right 3", "left 3")))
                 res["%s_N%d" % (demo, N)]["classified"] = {"feasible_point_found": r["feasible_point_found"], "smallest_violation": r["viol"], "from_start": r["start"],
                                                           "max_Topt": float(q.Tmax), "host_core_status": c["status"],
-                                                          "method": "SciPy SLSQP on the pinned model, seven starts (tests/independent.py:classify)"}
+                                                          "method": "SciPy SLSQP on the pinned model, four starts: window, straight line, window moved 3 m to either side (tests/independent.py:classify)"}
             except Exception as e:          # noqa: BLE001
                 res["%s_N%d" % (demo, N)]["classified"] = {"error": repr(e)}
     # the plan the reference repository shows in images/aStar_vs_openLoopOBCA.png (demo9, N = 50, Q = 0.5 I; fixture
@@ -400,12 +400,12 @@ def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=Fal
                                     max(1, min(192, os.cpu_count() or 1)))
                 same = [r for r in rows if not r["replay_differs"]]
                 res["stopped_infeasible_split"] = {
-                    "sample": "%d of the %d stopped rollouts (lowest world indices%s)" % (len(stopped), n_stopped, "" if len(stopped) == n_stopped else "; --classify-all for every one: profiles/r04_bench_default_run.json"),
+                    "sample": "%d of the %d stopped rollouts (lowest world indices%s)" % (len(stopped), n_stopped, "" if len(stopped) == n_stopped else "; --classify-all for every one"),
                     "classified": len(same), "feasible_point_exists_solver_failure": int(sum(r["feasible_point_found"] for r in same)),
                     "no_feasible_point_found": int(sum(not r["feasible_point_found"] for r in same)),
                     "host_replay_stops_elsewhere": len(rows) - len(same),
                     "solver_failures_world_step_variant_status": [list(r["tag"]) for r in same if r["feasible_point_found"]],
-                    "method": "host replay of each stopped rollout (structured core), last solve to SciPy SLSQP from three starts on the pinned model, %.1f s" % (time.time() - t1)}
+                    "method": "host replay of each stopped rollout (structured core), last solve to SciPy SLSQP from seven starts on the pinned model (window, straight line, last iterate, window moved 1.5 / 3 m to either side), %.1f s" % (time.time() - t1)}
             except Exception as e:          # noqa: BLE001
                 res["stopped_infeasible_split"] = {"error": repr(e)}
     return res

@@ -159,9 +159,10 @@ def lateral_points(p, d, ramp=3):
 def classify(job):
     """job = (p, last iterate of the product, tag): a feasible point from the window, a straight line, the last iterate, or the
     window moved 1.5 / 3 m to either side"""
-    p, z_last, tag = job
+    p, z_last, tag = job[:3]
+    kinds = job[3] if len(job) > 3 else ("window", "line", "last_iterate", "right 1.5", "left 1.5", "right 3", "left 3")
     best = None
-    for kind in ("window", "line", "last_iterate", "right 1.5", "left 1.5", "right 3", "left 3"):
+    for kind in kinds:
         if kind == "window":
             z0 = trajectory_start(p, p.xref)
         elif kind == "line":
