@@ -142,3 +142,14 @@ def test_F8_driver_trace(harness_golden, i):
             np.testing.assert_array_equal(np.asarray(mine["terminal_set"]), np.array(ref["terminal_set"]))
     np.testing.assert_array_equal(cl.xOpt, np.array(c["x_closed"]))
     assert cl.Ts_opt == c["Ts_opt_list"]
+
+
+def test_update_path_unknown_type_returns_zeros_like_the_reference():
+    """src/closed_loop.py:529-566: a reference type the routine does not know falls through every branch and the all-zero ref_x is
+    returned; the mirror does the same (with a warning), it does not raise"""
+    import warnings
+    cl = closedLoop(problemSetting("demo1"), solver=NoSolver())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ref = cl.update_path(0, cl.x0, cl.xF, 0, "no_such_type")
+    assert len(w) == 1 and not np.asarray(ref).any()

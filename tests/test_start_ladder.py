@@ -168,3 +168,17 @@ def test_c3_gated_batch_with_the_ladder_structured_core_against_dense_oracle():
         c = kkt_check.certificate(kkt_check.problem_of(b, i, N), got["z"][i], got["y"][i])
         for k in ("stationarity", "primal", "dual_sign", "complementarity"):
             assert c[k] <= 1e-6, (i, k, c)
+
+
+def test_out_of_range_start_fields_are_rejected_by_every_cpu_implementation(nlp_golden):
+    """include/obca_mpc.h: start_order outside OBCA_START_*, single_start outside 0 / 1 -> OBCA_E_INVAL.  The dense C oracle and the
+    host build of the core answer the same inputs with an error too (the oracle used to map them to defaults silently), and the numpy
+    spec raises: a parity test with a mistyped option cannot pass on one side only."""
+    case = [c for c in nlp_golden if c["name"] == "demo1_dyn_mpc6"][0]
+    for bad in (dict(start_order=4), dict(start_order=-1), dict(single_start=2)):
+        with pytest.raises(ValueError):
+            c_oracle.solve_batch(*_packed(case, **bad))
+        with pytest.raises(AssertionError):
+            native_build.lpi_solve(*_packed(case, **bad))
+    with pytest.raises(KeyError):
+        ipm_dense.solve(build(case), dict(start_order=7))

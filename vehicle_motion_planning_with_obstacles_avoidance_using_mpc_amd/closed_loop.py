@@ -219,7 +219,10 @@ class closedLoop:
                 path = self.path_solver.create_reference_path(self.path_solver.rebuild_path(route))
                 ref_x = np.asarray(path).T
             elif type != "":
-                raise ValueError("update_path: unknown reference type %r" % (type,))
+                # the reference returns its all-zero ref_x for a type it does not know (src/closed_loop.py:529-566): same here,
+                # with a warning instead of silence
+                import warnings
+                warnings.warn("update_path: unknown reference type %r -- the all-zero reference is returned, as the reference does" % (type,), stacklevel=2)
             return ref_x
         # allAviable == 1: resample the current reference to N_fix segments, recompute yaw, rescale the step
         ratio = int(self.N_fix / self.N_free)
