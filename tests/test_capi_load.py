@@ -70,3 +70,24 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "obca_mpc.h"\nint main(void) { obca_dims d; (void)d; return (int)sizeof(obca_params) == 0; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                     "-I", os.path.join(ge.ROOT, "include"), str(src)], check=True)
+
+
+def test_ctypes_mirror_of_obca_params_matches_the_header(lib, tmp_path):
+    """the Python mirror (_lib.ObcaParams) against the C header, field by field: a C program prints sizeof and every offsetof; and
+    obca_params_init (no GPU needed) leaves all zero + struct_size -- what a new ObcaParams() holds"""
+    import subprocess
+    fields = [f[0] for f in _lib.ObcaParams._fields_]
+    src = tmp_path / "o.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "obca_mpc.h"\nint main(void) {\n  printf("%zu\\n", sizeof(obca_params));\n'
+                   + "".join('  printf("%%zu\\n", offsetof(obca_params, %s));\n' % f for f in fields) + "  return 0;\n}\n")
+    exe = tmp_path / "o"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ge.ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    nums = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert nums[0] == ctypes.sizeof(_lib.ObcaParams)
+    assert nums[1:] == [getattr(_lib.ObcaParams, f).offset for f in fields]
+    assert fields[0] == "struct_size" and fields[-2:] == ["dodge", "terminal_screen"]
+    p = _lib.ObcaParams()
+    ctypes.memset(ctypes.byref(p), 0x5a, ctypes.sizeof(p))
+    lib.obca_params_init(ctypes.byref(p))
+    assert p.struct_size == nums[0] and bytes(p)[4:] == bytes(nums[0] - 4)
+    assert bytes(_lib.ObcaParams()) == bytes(p)
