@@ -157,7 +157,7 @@ def config_c3(B, N=20, start_order=0, classify=False):
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
     res = {"workload": "C3 (SURVEY 8d): N=%d, B=%d unique seeded instances per sub-batch" % (N, B),
-           "kernel": "four wavefronts per instance, two-sided Riccati sweep (default for shapes beyond the one-wavefront kernels)"}
+           "kernel": "free-time half (three obstacles): one wavefront per instance, row state in an HBM workspace (obca_ipm_kernel_gm1); gated half (five obstacles): four wavefronts per instance, LDS resident, two-sided Riccati sweep"}
     procs = max(1, min(48, (os.cpu_count() or 1) // 2))
     for name, gated in (("free_time_obca_mpc4", False), ("gated_obca_mpc6", True)):
         if (B, N, gated) not in _C3_BATCHES:

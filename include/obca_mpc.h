@@ -215,13 +215,16 @@ int64_t obca_dual_size(const obca_dims* dims);
 int obca_set_certificate_buffers(obca_handle* h, double* z, double* y);
 
 /* Kernel selection: 0 = auto (default; also env OBCA_MODE): one wavefront per instance when its rows fit the
- * wavefront's registers (<= 384 rows) and its working set one CU's LDS; else four wavefronts per instance when the
- * working set still fits the LDS (<= 1280 rows, e.g. N = 20 with five obstacles); else four wavefronts per instance with the
- * row state and every O(rows) array in an HBM workspace owned by the handle and only the O(N) blocks of the stage-serial
- * Riccati sweep in LDS (long horizons: N = 74 with five obstacles has 3976 rows); else (N > ~150) the lane-per-instance kernel.
+ * wavefront's registers (<= 384 rows) and its working set one CU's LDS; beyond that, shapes with at most three obstacles run one
+ * wavefront per instance with the row state in an HBM workspace owned by the handle (measured 6-33 % faster than four wavefronts
+ * there: the stage-serial sweep dominates and four times as many instances are in flight), shapes with more obstacles four
+ * wavefronts per instance while the working set still fits the LDS (<= 1280 rows, e.g. N = 20 with five obstacles); else four
+ * wavefronts per instance with the row state and every O(rows) array in the HBM workspace and only the O(N) blocks of the
+ * stage-serial Riccati sweep in LDS (long horizons: N = 74 with five obstacles has 3976 rows); else (N > ~150) the
+ * lane-per-instance kernel.  The choice is a function of the shape only.
  * 1 = one wavefront per instance; 2 = lane-per-instance (64 instances per wavefront, working set in an HBM workspace
  * owned by the handle; any shape); 3 = four wavefronts per instance, LDS resident; 4 = four wavefronts per instance, HBM
- * workspace.  Returns OBCA_E_LDS if mode 1 / 3 / 4 cannot hold the shape. */
+ * workspace; 5 = one wavefront per instance, HBM workspace.  Returns OBCA_E_LDS if mode 1 / 3 / 4 / 5 cannot hold the shape. */
 int obca_set_mode(obca_handle* h, int mode);
 
 /* Compile-time-shape instantiations.  For the problem shapes the reference's closed-loop driver produces with its nine demo

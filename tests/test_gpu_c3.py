@@ -198,3 +198,25 @@ def test_c3_fixed_time_moving_obstacles():
     assert n_tight >= 8                                       # observed 10 of 15 feasible ones
     # and, whatever the path, every converged answer is a KKT point of the reference-pinned model (N = 8 and N = 20:
     # tests/test_gpu_certificates.py::test_c3_instances_are_certified_at_N20)
+
+
+def test_one_wavefront_workspace_kernel_returns_the_four_wavefront_words_and_serves_three_obstacle_shapes():
+    """obca_ipm_kernel_gm1 (mode 5, round 5): one wavefront per instance, row state in the HBM workspace.  Same body, same words as
+    the four-wavefront kernels with the one-sided sweep (LDS resident and HBM workspace); in auto mode it serves the shapes beyond
+    the one-wavefront LDS kernel that have at most three obstacles (the free-time half of config C3), the four-wavefront LDS kernel
+    the others (the gated half)."""
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    for N, gated in ((20, False), (12, False), (10, True)):
+        b = sc.make_batch_c3(48, N, gated=gated, procs=8)
+        g1, g4, m4 = run(b, N, "global1"), run(b, N, "global", two_sided=False), run(b, N, "multiwave", two_sided=False)
+        for k in g1:
+            assert np.array_equal(g1[k], g4[k], equal_nan=True) and np.array_equal(g1[k], m4[k], equal_nan=True), (N, gated, k)
+        auto = run(b, N)
+        if not gated:
+            for k in g1:
+                assert np.array_equal(auto[k], g1[k], equal_nan=True), (N, k)          # auto = the one-wavefront workspace kernel
+        else:
+            two = run(b, N, "multiwave")                                                 # auto = four wavefronts, two-sided sweep
+            for k in two:
+                assert np.array_equal(auto[k], two[k], equal_nan=True), (N, k)
+        assert np.isin(g1["status"], (0, 1)).mean() > 0.9

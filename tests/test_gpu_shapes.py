@@ -89,6 +89,9 @@ def test_four_wavefront_instantiations_return_the_generic_kernels_words(gated):
     Riccati sweep) -- the instantiation against obca_ipm_kernel_mw_r3 / _mw_r5"""
     b = sc.make_batch_c3(64, 20, gated=gated, procs=8)
     s = BatchSolver(20, b["m"], max_batch=64)
+    if not gated:                      # auto mode runs three-obstacle shapes of this size on the one-wavefront HBM-workspace kernel (round 5)
+        assert not s.specialised
+        s.set_mode("multiwave")
     assert s.specialised
     for variant in ((6, 8) if gated else (4,)):
         got = _run(s, b, variant)

@@ -15,6 +15,7 @@ extern "C" __global__ void obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaL
 extern "C" __global__ void obca_ipm_kernel_mw_r3(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);          // four wavefronts per instance (obca_kernel_mw.hip)
 extern "C" __global__ void obca_ipm_kernel_mw_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
 extern "C" __global__ void obca_ipm_kernel_gm(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);             // four wavefronts, rows in an HBM workspace
+extern "C" __global__ void obca_ipm_kernel_gm1(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);            // one wavefront, rows in an HBM workspace
 // compile-time-shape instantiations of the one-wavefront kernel (csrc/obca_kernel_s*.hip; list: csrc/obca_device.h OBCA_SHAPES)
 #define OBCA_DECLARE_SHAPE_KERNEL(N_, O_, M_) extern "C" __global__ void obca_ipm_kernel_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3);
 OBCA_SHAPES(OBCA_DECLARE_SHAPE_KERNEL)
@@ -64,6 +65,15 @@ bool dims_ok(const obca_dims* d) {
         if (d->m[i] < 1 || d->m[i] > OBCA_MAX_EDGES) return false;
     return true;
 }
+
+// Auto mode, shapes beyond the one-wavefront LDS kernel (> 384 rows): ONE wavefront per instance with the row state in the HBM
+// workspace (obca_ipm_kernel_gm1) where an instance has at most three obstacles, the four-wavefront LDS kernel otherwise.  Measured
+// (round 5, tools/gpu_gm1_shapes.py, 8192 instances of the C3 generator): three obstacles / 6 rows per stage N = 12 / 16 / 20 / 26:
+// 114.6 / 151.6 / 178.7 / 255.5 ms against 152.9 / 182.8 / 194.0 / 270.7 ms on four wavefronts (with few rows per stage the stage-serial
+// sweep dominates, and four times as many instances in flight hide its latency); five obstacles / 14 rows per stage N = 8 ... 14:
+// 187 ... 276 ms against 131 ... 214 ms (the local blocks of five obstacles keep four wavefronts busy).  Same words as the
+// four-wavefront kernels with the one-sided sweep.  A function of the SHAPE only.
+bool auto_gm1(const obca_handle* h) { return h->mode == 0 && !h->wave_ok && h->gm_ok && h->dims.n_obs <= 3; }
 
 // (the carve-up itself: csrc/obca_device.h: obca_shape_sizes, shared with the kernels)
 int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off) {
@@ -136,8 +146,10 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     if (!guard.ok) { delete h; return OBCA_E_HIP; }
     // a kernel whose LDS request the runtime refuses is simply not offered (the lane kernel serves every shape)
     if (h->gm_ok && h->lds_bytes_gm > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(obca_ipm_kernel_gm), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)h->lds_bytes_gm) != hipSuccess) {
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(obca_ipm_kernel_gm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->lds_bytes_gm) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(obca_ipm_kernel_gm1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->lds_bytes_gm) != hipSuccess)) {
         (void)hipGetLastError();
         h->gm_ok = false;
     }
@@ -177,7 +189,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     if (const char* e = getenv("OBCA_TWO_SIDED")) { const int v = atoi(e); if (v >= -1 && v <= 1) h->two_sided = v; }
     if (const char* e = getenv("OBCA_MODE")) {
         const int m = atoi(e);                                     // out of range or not available for this shape: auto
-        if (m >= 0 && m <= 4 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok) && !(m == 4 && !h->gm_ok)) h->mode = m;
+        if (m >= 0 && m <= 5 && !(m == 1 && !h->wave_ok) && !(m == 3 && !h->mw_ok) && !((m == 4 || m == 5) && !h->gm_ok)) h->mode = m;
     }
     h->ws = nullptr; h->d_offm = nullptr;
     h->ws_stride = ((size_t)d->max_batch + 63) / 64 * 64;
@@ -205,8 +217,8 @@ extern "C" void obca_destroy(obca_handle* h) {
 }
 
 extern "C" int obca_set_mode(obca_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 4) return OBCA_E_INVAL;
-    if (mode == 4 && !h->gm_ok) return OBCA_E_LDS;
+    if (!h || mode < 0 || mode > 5) return OBCA_E_INVAL;
+    if ((mode == 4 || mode == 5) && !h->gm_ok) return OBCA_E_LDS;
     if (mode == 1 && !h->wave_ok) return OBCA_E_LDS;
     if (mode == 3 && !h->mw_ok) return OBCA_E_LDS;
     h->mode = mode;
@@ -249,7 +261,7 @@ extern "C" int obca_set_shape_specialisation(obca_handle* h, int on) {
 
 extern "C" int obca_shape_is_specialised(const obca_handle* h) {
     if (!h) return OBCA_E_INVAL;
-    if (!h->specialise || h->mode == 2 || h->mode == 4) return 0;
+    if (!h->specialise || h->mode == 2 || h->mode == 4 || h->mode == 5 || auto_gm1(h)) return 0;
     const bool mw = h->mode == 3 || (h->mode == 0 && !h->wave_ok && h->mw_ok);
     return mw ? (h->shape_kernel_mw ? 1 : 0) : (h->wave_ok && h->shape_kernel ? 1 : 0);
 }
@@ -333,7 +345,7 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     // (every access is an L2/HBM round trip at one wave per SIMD) and 4-10x slower where both run
     if (h->mode == 1 && !h->wave_ok) return OBCA_E_LDS;
     if (h->mode == 3 && !h->mw_ok) return OBCA_E_LDS;
-    if (h->mode == 4 || (h->mode == 0 && !h->wave_ok && !h->mw_ok && h->gm_ok)) {
+    if (h->mode == 4 || h->mode == 5 || auto_gm1(h) || (h->mode == 0 && !h->wave_ok && !h->mw_ok && h->gm_ok)) {
         // shapes beyond the LDS: four wavefronts per instance, rows and O(rows) arrays in the handle's HBM workspace
         if (!h->gm_ok) return OBCA_E_LDS;
         if (!h->gm_ws && hipMalloc(&h->gm_ws, sizeof(double) * (size_t)h->gm_doubles * (size_t)h->dims.max_batch) != hipSuccess) {
@@ -343,7 +355,8 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
         L.inst_off = h->inst_off_gm;
         L.gm_ws = h->gm_ws; L.gm_stride = h->gm_doubles;
         ObcaLaunch L2 = L;
-        hipLaunchKernelGGL(obca_ipm_kernel_gm, dim3(B), dim3(256), (size_t)h->lds_bytes_gm, (hipStream_t)hip_stream, L, L2, L2);
+        if (h->mode == 5 || auto_gm1(h)) { L.two_sided = 0; L2.two_sided = 0; hipLaunchKernelGGL(obca_ipm_kernel_gm1, dim3(B), dim3(64), (size_t)h->lds_bytes_gm, (hipStream_t)hip_stream, L, L2, L2); }
+        else hipLaunchKernelGGL(obca_ipm_kernel_gm, dim3(B), dim3(256), (size_t)h->lds_bytes_gm, (hipStream_t)hip_stream, L, L2, L2);
         return hipGetLastError() == hipSuccess ? OBCA_OK : OBCA_E_HIP;
     }
     // one wavefront per instance where the rows fit its registers; four wavefronts (one CU) per instance for bigger

@@ -2649,6 +2649,9 @@ OBCA_TU_SHAPE(OBCA_DEFINE_SHAPE_KERNEL)
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r4(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<4, OBCA_LOOP_R4>(A, A2, A3); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r5(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<5, OBCA_LOOP_R56>(A, A2, A3); }
 extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_r6(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<6, OBCA_LOOP_R56>(A, A2, A3); }
+// rows in an HBM workspace like obca_ipm_kernel_gm, but ONE wavefront per instance (mode 5): up to four instances per CU where the
+// O(N) blocks of the sweep leave the LDS room, instead of one
+extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_gm1(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { solve_with_escalation<0, OBCA_LOOP_GM>(A, A2, A3); }
 
 // ================================================================== fused closed loop
 // One wavefront runs one step of one rollout at a time: lane 0 runs the harness of csrc/obca_rollout_core.h around

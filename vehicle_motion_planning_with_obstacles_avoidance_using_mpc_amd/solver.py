@@ -113,11 +113,12 @@ class BatchSolver:
         if mode is not None:
             self.set_mode(mode)
 
-    MODES = {"auto": 0, "wave": 1, "lane": 2, "multiwave": 3, "global": 4}
+    MODES = {"auto": 0, "wave": 1, "lane": 2, "multiwave": 3, "global": 4, "global1": 5}
 
     def set_mode(self, mode):
         """'auto' | 'wave' (one wavefront per instance, LDS) | 'multiwave' (four wavefronts per instance, LDS) |
-        'lane' (64 instances per wavefront, HBM workspace)"""
+        'lane' (64 instances per wavefront, HBM workspace) | 'global' / 'global1' (four wavefronts / one wavefront per instance,
+        row state in an HBM workspace)"""
         _lib.check(self.lib.obca_set_mode(self._h, self.MODES.get(mode, mode)))
 
     def set_two_sided_sweep(self, on):
