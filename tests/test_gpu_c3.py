@@ -88,8 +88,9 @@ def test_two_sided_sweep_gives_the_one_sided_answers():
 
 
 def test_c3_shapes_run_on_the_lds_kernel_and_agree_with_the_lane_kernel():
-    """N = 20: 694 rows (free-time part) and 1114 rows (gated part, 158.7 KB of LDS) -- auto mode must pick the
-    four-wavefront kernel, and its answers must be the lane kernel's"""
+    """N = 20: 694 rows (free-time part) and 1114 rows (gated part, 158.7 KB of LDS) -- both fit the four-wavefront LDS kernel; auto
+    mode picks it for the gated part (five obstacles) and the one-wavefront HBM-workspace kernel for the free-time part (three
+    obstacles; round 5), and the answers must be the lane kernel's"""
     import ctypes
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import _lib, scenarios as sc
     lib = _lib.load()
@@ -101,7 +102,8 @@ def test_c3_shapes_run_on_the_lds_kernel_and_agree_with_the_lane_kernel():
             d.m[i] = v
         assert lib.obca_lds_bytes(ctypes.byref(d)) + 64 <= 160 * 1024
         a, m, l = run(b, 20), run(b, 20, "multiwave"), run(b, 20, "lane")
-        assert np.array_equal(a["xopt"], m["xopt"]) and np.array_equal(a["iters"], m["iters"])      # auto == multiwave
+        same_kernel = m if gated else run(b, 20, "global1")
+        assert np.array_equal(a["xopt"], same_kernel["xopt"]) and np.array_equal(a["iters"], same_kernel["iters"])      # auto == multiwave / global1
         both = np.isin(m["status"], (0, 1)) & np.isin(l["status"], (0, 1))
         assert both.mean() > (0.93 if gated else 0.97)          # measured at 8192: 99.6 % / 100 % (bench.py config_c3)
         # two implementations of one algorithm (different expression forms => different roundoff): on a 150-190-iteration
