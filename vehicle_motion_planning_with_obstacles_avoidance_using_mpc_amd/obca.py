@@ -33,10 +33,12 @@ class obca:
         key = (int(N), tuple(m))
         if key not in self._solvers:
             s = BatchSolver(N, m, max_batch=1)
-            try:                      # a batch of one leaves the GPU idle: give the instance a whole CU (four
-                s.set_mode("multiwave")   # wavefronts), which shortens the call; same iterates as one wavefront
-            except RuntimeError:
-                pass                  # shape beyond the LDS: auto mode picks the lane kernel
+            for mode in ("multiwave", "global"):      # a batch of one leaves the GPU idle: give the instance a whole CU (four
+                try:                                  # wavefronts; LDS resident, or with the rows in the HBM workspace where the shape
+                    s.set_mode(mode)                  # is beyond the LDS), which shortens the call; same words as one wavefront
+                    break
+                except RuntimeError:
+                    pass                              # neither holds the shape: auto mode (the lane kernel)
             self._solvers[key] = s
         return self._solvers[key]
 
