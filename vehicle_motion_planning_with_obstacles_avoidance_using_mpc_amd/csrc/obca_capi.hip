@@ -71,7 +71,9 @@ bool dims_ok(const obca_dims* d) {
 // (round 5, tools/gpu_gm1_shapes.py, 8192 instances of the C3 generator): three obstacles / 6 rows per stage N = 12 / 16 / 20 / 26:
 // 114.6 / 151.6 / 178.7 / 255.5 ms against 152.9 / 182.8 / 194.0 / 270.7 ms on four wavefronts (with few rows per stage the stage-serial
 // sweep dominates, and four times as many instances in flight hide its latency); five obstacles / 14 rows per stage N = 8 ... 14:
-// 187 ... 276 ms against 131 ... 214 ms (the local blocks of five obstacles keep four wavefronts busy).  Same words as the
+// 187 ... 276 ms against 131 ... 214 ms (the local blocks of five obstacles keep four wavefronts busy); four obstacles / 10 rows per stage,
+// obca_mpc6 / 8, N = 10 ... 20: 140 ... 302 ms against 107 ... 179 ms; three obstacles with the fixed-time variants gain like the free-time
+// one (tools/gpu_gm1_four.py).  Same words as the
 // four-wavefront kernels with the one-sided sweep.  A function of the SHAPE only.
 bool auto_gm1(const obca_handle* h) { return h->mode == 0 && !h->wave_ok && h->gm_ok && h->dims.n_obs <= 3; }
 
