@@ -316,7 +316,7 @@ def reference_gif_leg():
 
 
 def start_order_leg(solver, dv, out0, B, order, steps=3):
-    """another obca_params.start_order on the headline batch ("window": the reference window as the first start; "zeros": the
+    """another obca_params.start_order on the headline batch ("x0": x0 first, obca_mpc4's default until obca_mpc 0.4; "zeros": the
     reference's literal all-zero start first, the default until obca_mpc 0.1): throughput, and how many instances end at the
     optimum the default order finds."""
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
@@ -567,7 +567,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2 generator (SURVEY 8d): demo1 corridor, 2 wall rows + 1 random box (M=%d), "
-                                   "random start along an A*-like lattice path, obca_mpc4, default start ladder (x0 -> window -> zeros), seed %d"
+                                   "random start along an A*-like lattice path, obca_mpc4, default start ladder (reference window -> x0 -> zeros), seed %d"
                                    % (M, sc.SEED0),
                        "batch_per_gpu": B, "horizon_N": N, "obstacles": 3, "variant": "obca_mpc4",
                        "parallelism": "shard%d" % world},
@@ -618,13 +618,13 @@ def main():
                 line["independent_solver"] = {"error": repr(e)}
         if dist is None and args.closed_loop_rollouts > 0:
             # secondary figures: a failure in one of them must not cost the headline line
-            def window_first_all():
-                r = start_order_leg(solver, dv, out, B, "window")
-                r["note"] = "obca_params.start_order = OBCA_START_WINDOW_FIRST: the reference window as the first start of every solve (NOT the default)"
-                r["config_c3"] = config_c3(B, start_order="window")
-                ol = open_loop(start_order="window")
+            def x0_first_all():
+                r = start_order_leg(solver, dv, out, B, "x0")
+                r["note"] = "obca_params.start_order = OBCA_START_X0_FIRST: x0 first for every variant -- for obca_mpc4 the default until obca_mpc 0.4, i.e. the configuration BENCH_r01 ... BENCH_r04 were measured in (NOT the default)"
+                r["config_c3"] = config_c3(B, start_order="x0")
+                ol = open_loop(start_order="x0")
                 r["open_loop"] = {k: v for k, v in ol.items() if isinstance(v, dict) and "seconds" in v}
-                c5 = closed_loop_c5(args.closed_loop_rollouts, start_order="window")
+                c5 = closed_loop_c5(args.closed_loop_rollouts, start_order="x0")
                 r["closed_loop"] = {k: c5[k] for k in ("value", "unit", "seconds", "converged_steps", "attempted_steps", "rollouts_to_step_cap", "rollouts_stopped_infeasible", "mean_ipm_iters") if k in c5}
                 return r
 
@@ -634,7 +634,7 @@ def main():
                 return r
             extras = (("reference_gif", reference_gif_leg),
                       ("reference_report_figures", report_figures_leg),
-                      ("window_first", window_first_all),
+                      ("x0_first", x0_first_all),
                       ("zeros_first", zeros_first),
                       ("open_loop", lambda: open_loop(classify=not args.no_cpu_baseline)),
                       ("config_c3", lambda: config_c3(B, classify=not args.no_cpu_baseline)),

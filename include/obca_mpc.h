@@ -120,18 +120,19 @@ void obca_params_init(obca_params* p);
 
 /* obca_params.start_order */
 enum {
-    OBCA_START_DEFAULT = 0,            /* obca_mpc4: x0 -> window -> zeros; obca_mpc6 / obca_mpc8: window -> x0 -> zeros.  The free-time
-                                          problem has one optimum on every workload measured and the x0 start needs nothing but x0;
-                                          the fixed-time problems have several, and from the window the solver ends at the lower one far
-                                          more often (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER).  Two exceptions keep x0 first for every
-                                          variant: single_start = 1 (a caller with its own fallback wants the start that fails fastest:
-                                          the closed loop's obca_mpc6 before obca_mpc8) and obca_set_warm_start (the stored plan stands
-                                          for x0). */
-    OBCA_START_WINDOW_FIRST = 1,       /* window -> x0 -> zeros: fastest where the window is a plausible trajectory
-                                          (closed loops along an A* path)                          */
+    OBCA_START_DEFAULT = 0,            /* window -> x0 -> zeros for every variant.  obca_mpc6 / obca_mpc8 have several local optima, and from the
+                                          window the solver ends at the lower one far more often; obca_mpc4 has one optimum on every workload
+                                          measured -- all 8192 headline instances, the free-time half of config C3, every free-time step of the
+                                          five reference-held runs end where they end from x0 -- and reaches it from the window in a third of the
+                                          iterations (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER; x0 first was the obca_mpc4 default of obca_mpc 0.4).
+                                          Two exceptions keep x0 first for every variant: single_start = 1 (a caller with its own fallback wants the
+                                          start that fails fastest: the closed loop's obca_mpc6 before obca_mpc8) and obca_set_warm_start (the stored
+                                          plan stands for x0).  A caller whose reference window is no trajectory (start and goal only: the open-loop
+                                          plan) is served better by OBCA_START_X0_FIRST. */
+    OBCA_START_WINDOW_FIRST = 1,       /* window -> x0 -> zeros, also for single-start and warm-started calls */
     OBCA_START_ZEROS_FIRST = 2,        /* zeros -> window -> x0: the reference's literal start first (the default of
                                           obca_mpc 0.1)                                            */
-    OBCA_START_X0_FIRST = 3            /* x0 -> window -> zeros for every variant (the default of obca_mpc 0.2 / 0.3) */
+    OBCA_START_X0_FIRST = 3            /* x0 -> window -> zeros for every variant (the default of obca_mpc 0.2 / 0.3; obca_mpc4's until 0.4) */
 };
 
 
@@ -376,7 +377,8 @@ int obca_rasterise_batch(const double* boxes, int32_t B, int32_t K, double resol
                          uint8_t* grid, void* hip_stream);
 
 const char* obca_strerror(int code);
-/* "obca_mpc 0.5 (gfx950)": 0.5 = obca_params.struct_size (first member; obca_params_init), the dodge rung and the terminal-set screen;
+/* "obca_mpc 0.5 (gfx950)": 0.5 = obca_params.struct_size (first member; obca_params_init), the dodge rung and the terminal-set screen,
+ * OBCA_START_DEFAULT = the window first for obca_mpc4 too, kernel mode 5;
  * 0.2 = the start ladder (start_order / single_start / patience / retry_iter replace restart); 0.3 = second
  * level of the penalty escalation, compile-time-shape instantiations, obca_rollouts_queue_mode; 0.4 = OBCA_START_DEFAULT per variant
  * (OBCA_START_X0_FIRST moved from 0 to 3) */

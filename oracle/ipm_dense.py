@@ -305,7 +305,7 @@ def solve(p, opts=None, trace=None):
     """The elastic IPM run through the START LADDER (same rule in oracle/obca_oracle.c, csrc/obca_lpi_core.h:run_instance and
     the wave kernels; include/obca_mpc.h: start_order, single_start, patience, retry_iter):
 
-    * the starts of the order (default: x0 -> reference window -> zeros) are tried one after the other until one ends at a
+    * the starts of the order (default: reference window -> x0 -> zeros) are tried one after the other until one ends at a
       feasible point.  IPOPT answers a solve that ends at an infeasible stationary point of its merit function, in a
       line-search failure or at the iteration limit with its feasibility-restoration phase; measured on such instances the
       restoration problem min ||c||_1 + zeta/2 ||D(x - x_R)||^2 started AT the stationary point x_R does not move (the l1
@@ -328,8 +328,8 @@ def solve(p, opts=None, trace=None):
         return _screened(p, short)
     order = opts.get("start_order", 0)
     order = ORDER_NAMES.get(order, order)
-    if order == 0:                 # the default: x0 first for the free-time problem, the window first for the fixed-time ones
-        order = 3 if (p.variant == 4 or opts.get("single_start")) else 1          # (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER)
+    if order == 0:                 # the default: the window first for every variant; x0 first for a single-start call
+        order = 3 if opts.get("single_start") else 1          # (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER)
     kinds = START_ORDERS[order]
     if opts.get("single_start"):
         kinds = kinds[:1]

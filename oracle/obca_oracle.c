@@ -367,7 +367,7 @@ enum { KIND_X0 = 0, KIND_WINDOW = 1, KIND_ZEROS = 2, KIND_DODGE_R = 3, KIND_DODG
 #define DODGE_OFFSET 3.0          /* csrc/obca_device.h: OBCA_DODGE_OFFSET */
 #define DODGE_RAMP 3
 #define DODGE_MIN_SPARE 0.1       /* csrc/obca_device.h: OBCA_DODGE_MIN_SPARE */
-/* index: the EFFECTIVE order 1, 2, 3 (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER; 0 = default: 3 for obca_mpc4, 1 for obca_mpc6 / 8) */
+/* index: the EFFECTIVE order 1, 2, 3 (csrc/obca_device.h: OBCA_EFFECTIVE_ORDER; 0 = default: 1 -- the window first -- for every variant, 3 for a single-start call) */
 static const int START_ORDERS[4][3] = {{KIND_X0, KIND_WINDOW, KIND_ZEROS}, {KIND_WINDOW, KIND_X0, KIND_ZEROS}, {KIND_ZEROS, KIND_WINDOW, KIND_X0}, {KIND_X0, KIND_WINDOW, KIND_ZEROS}};
 #define KAPPA_MU 0.2
 #define THETA_MU 1.5
@@ -928,7 +928,7 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
            converged with elastic variables left repeats the same start with rho x 100 and, if elastic variables still remain, with rho x 1000
            (the next start begins at the base penalty) */
         const int order0 = prm->start_order;
-        const int order = order0 != 0 ? order0 : ((p.variant == 4 || prm->single_start) ? 3 : 1);
+        const int order = order0 != 0 ? order0 : (prm->single_start ? 3 : 1);      /* csrc/obca_device.h: OBCA_EFFECTIVE_ORDER */
         const int nstarts = prm->single_start ? 1 : 3;
         const int max_iter_v = p.freeT ? o.max_iter_free : o.max_iter_fixed;
         const int pat = prm->patience > 0 ? prm->patience : PATIENCE(N), ret = prm->retry_iter > 0 ? prm->retry_iter : RETRY_ITER(N);

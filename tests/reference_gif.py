@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # Consecutive steps whose cumulative free time the GIF and this build share, by start order (include/obca_mpc.h: start_order) and
 # engine -- the ONE place these figures live (tests/test_reference_gif.py, tests/test_gpu_reference_gif.py and bench.py read them):
-#   "default" (x0 first for obca_mpc4, the window first for obca_mpc6 / 8), "x0" and "window": 69 steps on every engine; at step 70 IPOPT's own answer is the one that is not the best optimum
+#   "default" (the window first; x0 first for the closed loop's single-start obca_mpc6), "x0" and "window": 69 steps on every engine; at step 70 IPOPT's own answer is the one that is not the best optimum
 #       (its Ts_opt 2.11 s against 1.63 s here, which SLSQP confirms from the window), after which the run follows the GIF's
 #       clock at a constant distance (< 0.5 s) and reaches the goal after 84 steps like the reference's;
 #   "zeros" (the reference's literal all-zero start first): at least 47 steps with the structured core / the kernels and 42 with

@@ -17,7 +17,7 @@ def _replay(order, n):
 
 @pytest.mark.parametrize("order", ["default", "x0", "window", "zeros"])
 def test_product_path_shows_the_references_digits(order):
-    """default ladder (x0 first) and window first: 69 consecutive steps; the literal zero start first: 47"""
+    """default ladder (the window first), x0 first and window first: 69 consecutive steps; the literal zero start first: 47"""
     fx = reference_gif.fixture()
     n = reference_gif.MATCHED[order]["gpu"]
     cum, xs, _ = _replay(order, n)

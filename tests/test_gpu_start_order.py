@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("order,iters_vs_default", [("window", 0.5), ("zeros", 1.6)])
+@pytest.mark.parametrize("order,iters_vs_default", [("x0", 3.5), ("zeros", 4.5)])
 def test_other_orders_match_the_oracle_and_the_default_optima(order, iters_vs_default):
     import torch
     from oracle import c_oracle
@@ -25,8 +25,11 @@ def test_other_orders_match_the_oracle_and_the_default_optima(order, iters_vs_de
     st, it = out.status.cpu().numpy(), out.iters.cpu().numpy()
     xo, ts = out.xopt.cpu().numpy(), out.ts_opt.cpu().numpy()
     assert np.all((st == 0) | (st == 1)) and np.all((s0 == 0) | (s0 == 1))
-    ratio = it.mean() / base.iters.float().mean().item()                     # measured: window 17, x0 50, zeros 64 iterations
-    assert ratio < iters_vs_default and (order == "window" or ratio > 1.0)
+    ratio = it.mean() / base.iters.float().mean().item()                     # measured: window (the default) 17, x0 50, zeros 64 iterations
+    assert 1.5 < ratio < iters_vs_default
+    same = s.solve(*args, SolverParams(start_order="window"))                # the default order IS the window first
+    torch.cuda.synchronize()
+    assert np.array_equal(same.xopt.cpu().numpy(), x0) and np.array_equal(same.iters.cpu().numpy(), base.iters.cpu().numpy())
     # same optimum as the default order of the starts, every instance (solver tolerance 1e-8)
     np.testing.assert_allclose(ts, t0, rtol=1e-6, atol=0)
     np.testing.assert_allclose(xo, x0, rtol=0, atol=1e-5)

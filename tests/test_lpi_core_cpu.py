@@ -78,11 +78,11 @@ def test_penalty_escalation_solves_the_open_loop_problem():
     assert x[1].max() > 5.5 and abs(x[0, -1] - 38.0) < 1e-6                    # goes round the box, reaches the goal
     c = s.calls[-1]
     ref = c_oracle.solve_batch(4, 10, c["m"], c["x0"][None], c["u0"][None], c["xref"][None], c["A"][None], c["b"][None],
-                               [c["Ts"]], None, threads=1)
+                               [c["Ts"]], None, c_oracle.default_params(start_order="x0"), threads=1)      # (as the open-loop driver asks: x0 first)
     assert ref["status"][0] == 0                     # ~340 iterations over the two passes; the paths differ by roundoff
     assert np.max(np.abs(ref["xopt"][0] - x)) < 1e-5 and abs(ref["ts_opt"][0] - cl.Ts_opt) < 1e-6
     no_esc = native_build.lpi_solve(4, 10, c["m"], c["x0"][None], c["u0"][None], c["xref"][None], c["A"][None], c["b"][None],
-                                    [c["Ts"]], None, c_oracle.default_params(rho=1e6))
+                                    [c["Ts"]], None, c_oracle.default_params(rho=1e6, start_order="x0"))
     assert no_esc["status"][0] == 0 and no_esc["iters"][0] < c["iters"]         # the escalated pass alone
 
 

@@ -41,7 +41,7 @@ def _check(fx, engine, order, n):
 @pytest.mark.parametrize("engine", ["lpi", "oracle"])
 @pytest.mark.parametrize("order", ["default", "x0", "window"])
 def test_cpu_solvers_replay_69_steps_of_the_reference_run(fx, engine, order):
-    """The default start ladder (x0 -> window -> zeros) and the window-first order: engine "oracle" is the dense C oracle
+    """The default start ladder (window -> x0 -> zeros), the x0-first and the window-first order: engine "oracle" is the dense C oracle
     (oracle/obca_oracle.c) -- this is what pins the ORACLE to the reference; engine "lpi" the structured core the kernels are
     built from, compiled for the host.  69 chained solves show the reference's digits."""
     n = reference_gif.MATCHED[order][engine]

@@ -73,7 +73,7 @@ def test_monte_carlo_worlds_follow_the_mirror():
     assert out["steps"].sum() >= 8
 
 
-@pytest.mark.parametrize("order", ["window", "zeros"])
+@pytest.mark.parametrize("order", ["window", "x0", "zeros"])
 def test_other_start_orders_follow_the_mirror(order):
     """obca_params.start_order (include/obca_mpc.h): the harness hands obca_mpc6 the first start of the order only
     (single_start), obca_mpc4 / obca_mpc8 the whole ladder -- as the Python mirror does per call"""
@@ -86,15 +86,16 @@ def test_other_start_orders_follow_the_mirror(order):
 
 def test_warm_start_option_reaches_the_same_plans_in_fewer_iterations():
     """obca_rollouts_set_warm_start (NOT reference behaviour, off by default): steps start from the shifted previous
-    plan.  On static worlds the closed-loop trajectory is the cold-start one to solver tolerance, at a fraction of
-    the interior-point iterations."""
+    plan.  On static worlds the closed-loop trajectory is the cold-start one to solver tolerance, in fewer
+    interior-point iterations."""
     w = pack_worlds([make_world_c5(i, n_dyn=0) for i in range(6)])
     cold = native_build.rollout_run(w, 5, c_oracle.default_params(), 12)
     warm = native_build.rollout_run(w, 5, c_oracle.default_params(), 12, warm_mu=0.1)
     assert np.array_equal(cold["steps"], warm["steps"]) and np.all(cold["steps"] == 12)
     np.testing.assert_allclose(warm["x_closed"][:, :13], cold["x_closed"][:, :13], rtol=0, atol=1e-5)
     np.testing.assert_array_equal(warm["iters"][:, 0], cold["iters"][:, 0])        # step 0 is always a cold start
-    assert warm["iters"][:, 1:12].mean() < 0.5 * cold["iters"][:, 1:12].mean()
+    # (the cold start of round 5 is the reference window: 16 iterations per step against the warm start's 12; with x0 first it was 40)
+    assert warm["iters"][:, 1:12].mean() < 0.85 * cold["iters"][:, 1:12].mean()
 
 
 def test_history_export_matches_the_mirror_lists():

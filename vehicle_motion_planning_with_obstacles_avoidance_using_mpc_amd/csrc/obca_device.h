@@ -80,16 +80,21 @@
 /* transient, kernel-internal: a feasible answer of the first dodge pass waiting for the second one (never returned to a caller) */
 #define OBCA_STATUS_DODGE_OK 3
 #define OBCA_STATUS_DODGE_ACC 4
-/* obca_params.start_order = OBCA_START_DEFAULT (0) means: x0 first for the free-time problem (obca_mpc4: one optimum on the bench
-   workloads, and the x0 start needs nothing but x0), the reference window first for the fixed-time ones (obca_mpc6 / obca_mpc8: several
-   local optima -- measured on 2048 gated instances at N = 20 the window start ends lower than x0 on 73-76 % of those both solve and
-   solves 95 % alone against 80 %, profiles/r04_start_quality.txt).  A caller's warm start stands for x0, so it keeps x0's order; so does
+/* obca_params.start_order = OBCA_START_DEFAULT (0) means: the reference window first for every variant (window -> x0 -> zeros).
+   obca_mpc6 / obca_mpc8 (round 4): several local optima -- measured on 2048 gated instances at N = 20 the window start ends lower than
+   x0 on 73-76 % of those both solve and solves 95 % alone against 80 % (profiles/r04_start_quality.txt).  obca_mpc4 (round 5): one
+   optimum on every workload measured -- from the window all 8192 headline instances, all 8192 free-time instances of C3 and every
+   free-time step of the five reference-held runs end where they end from x0 -- in a third of the iterations (17 against 50 on the
+   headline batch, 20 against 64 at N = 20).  Two exceptions keep x0 first for every variant: a caller's warm start stands for x0, and
    a single-start call -- its caller has a fallback of its own and is served best by the start that fails fastest (C5, where the
    terminal set makes obca_mpc6 fail on half of the gated steps: 0.546 s with x0 there, 0.648 s with the window). */
 #ifndef OBCA_DEFAULT_ORDER_MPC8
 #define OBCA_DEFAULT_ORDER_MPC8 1
 #endif
-#define OBCA_EFFECTIVE_ORDER(o, variant, warm, single) ((o) != 0 ? (o) : (((variant) == 4 || (warm) || (single)) ? 3 : (variant) == 8 ? OBCA_DEFAULT_ORDER_MPC8 : 1))
+#ifndef OBCA_DEFAULT_ORDER_MPC4
+#define OBCA_DEFAULT_ORDER_MPC4 1
+#endif
+#define OBCA_EFFECTIVE_ORDER(o, variant, warm, single) ((o) != 0 ? (o) : (((warm) || (single)) ? 3 : (variant) == 4 ? OBCA_DEFAULT_ORDER_MPC4 : (variant) == 8 ? OBCA_DEFAULT_ORDER_MPC8 : 1))
 /* kind of start s = 0, 1, 2 of the EFFECTIVE order o = 1, 2, 3 (two bits per start): window/x0/zeros, zeros/window/x0, x0/window/zeros */
 #define OBCA_START_KIND(o, s) (((((o) == 1) ? 0x21 : ((o) == 2) ? 0x06 : 0x24) >> (2 * (s))) & 3)
 /* the caller's optional warm start (obca_set_warm_start) takes the place of the first COLD start of the order */

@@ -17,9 +17,9 @@ from .solver import BatchSolver, SolverParams, pack_reference_call
 class obca:
     def __init__(self):
         self._solvers = {}
-        # The start ladder of every solve (include/obca_mpc.h: start_order): "default" -- obca_mpc4 x0 -> reference window -> zeros,
-        # obca_mpc6 / obca_mpc8 window -> x0 -> zeros; "x0" / "window" / "zeros": that start first for every variant ("zeros" = the
-        # reference's literal all-zero start, src/obca.py:856).
+        # The start ladder of every solve (include/obca_mpc.h: start_order): "default" -- reference window -> x0 -> zeros for every variant
+        # (x0 first for single-start calls); "x0" / "window" / "zeros": that start first for every variant ("zeros" = the reference's
+        # literal all-zero start, src/obca.py:856).
         self.start_order = "default"
         # True: every call runs the first start of the order only.  A driver that answers a failed obca_mpc6 with obca_mpc8
         # itself (this package's closedLoop) asks for that per call instead: obca_mpc6(..., single_start=True).

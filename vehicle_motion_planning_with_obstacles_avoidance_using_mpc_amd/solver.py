@@ -49,8 +49,8 @@ class SolverParams:
         self.tol, self.rho, self.feas_tol = float(tol), float(rho), float(feas_tol)
         self.max_iter_free, self.max_iter_fixed = int(max_iter_free), int(max_iter_fixed)
         self.max_soc = int(max_soc)            # 0 = IPOPT's default (4), negative = no second-order correction
-        # the start ladder (include/obca_mpc.h): start_order "default" (obca_mpc4: x0 -> window -> zeros; obca_mpc6 / obca_mpc8: window -> x0
-        # -> zeros; x0 first also for a single start and for warm starts) | "x0" | "window" | "zeros" (that start first for every
+        # the start ladder (include/obca_mpc.h): start_order "default" (window -> x0 -> zeros for every variant;
+        # x0 first for a single start and for warm starts) | "x0" | "window" | "zeros" (that start first for every
         # variant) or the OBCA_START_* value; single_start: the first start only; patience / retry_iter: 0 = the defaults
         # 500 + 10 N / 300 + 10 N; dodge: the ladder's last rung for obca_mpc6 / 8 (the window moved to either side); terminal_screen:
         # obca_mpc6 whose terminal set cannot be reached is answered without a solve
