@@ -92,7 +92,7 @@ def test_c5_calls_screened_alike_and_identical_to_the_host_core():
         assert np.array_equal(dev["iters"] == 0, scr)
         for k in ("xopt", "uopt", "ts_opt"):
             assert np.array_equal(dev[k][scr], host[k][scr]), k          # screened: x0 at every stage, zero inputs -- the same words
-        assert np.array_equal(dev["info"][scr], host["info"][scr])
+        np.testing.assert_allclose(dev["info"][scr], host["info"][scr], rtol=1e-9, atol=1e-15)      # (the shortfall holds cos(theta_0): device libm against the host's)
         ok = np.isin(host["status"], (0, 1))
         np.testing.assert_allclose(dev["xopt"][ok], host["xopt"][ok], rtol=0, atol=1e-5)
     assert n_scr >= 20
