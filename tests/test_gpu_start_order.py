@@ -95,3 +95,33 @@ def test_other_orders_closed_loop_fused_equals_lockstep_and_host(order):
         k = host["steps"][i]
         np.testing.assert_allclose(res[0]["x_closed"][i, :k + 1], host["x_closed"][i, :k + 1], rtol=0, atol=1e-7)
         np.testing.assert_allclose(res[0]["T_closed"][i, :k], host["T_closed"][i, :k], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("workload", ["c2_other_seeds", "c2_three_boxes", "c3_free_N12"])
+def test_free_time_problem_ends_at_one_optimum_from_window_and_x0(workload):
+    """the default order starts obca_mpc4 at the reference window (round 5) because it ends where the x0 start ends: checked here on
+    batches the choice was NOT made on -- other seeds of the headline generator, its three-box sub-configuration (12 rows per stage),
+    the free-time half of the C3 generator at N = 12"""
+    import torch
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+    B = 1024
+    if workload == "c2_other_seeds":
+        b, N = sc.make_batch(B, 5, first=500000), 5
+    elif workload == "c2_three_boxes":
+        b, N = sc.make_batch(B, 5, three_boxes=True, first=300000), 5
+    else:
+        b, N = sc.make_batch_c3(B, 12, first=200000, gated=False, procs=8), 12
+    s = BatchSolver(N, b["m"], max_batch=B)
+    args = (b["variant"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"])
+    w = s.solve(*args, SolverParams())
+    xw, tw, sw, iw = w.xopt.cpu().numpy(), w.ts_opt.cpu().numpy(), w.status.cpu().numpy(), w.iters.cpu().numpy()
+    x = s.solve(*args, SolverParams(start_order="x0"))
+    torch.cuda.synchronize()
+    xx, tx, sx, ix = x.xopt.cpu().numpy(), x.ts_opt.cpu().numpy(), x.status.cpu().numpy(), x.iters.cpu().numpy()
+    both = np.isin(sw, (0, 1)) & np.isin(sx, (0, 1))
+    assert both.mean() > 0.995 and np.isin(sw, (0, 1)).sum() >= np.isin(sx, (0, 1)).sum() - 1
+    same = (np.abs(xw - xx).reshape(B, -1).max(1) <= 1e-5) & (np.abs(tw - tx) <= 1e-6 * np.maximum(1.0, np.abs(tx)))
+    assert same[both].mean() >= 0.998, (workload, int((~same & both).sum()))
+    assert iw[both].mean() < 0.6 * ix[both].mean()
+    s.close()
