@@ -442,7 +442,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--classify-all", action="store_true",
-                    help="classify EVERY stopped C5 rollout on the host (about three minutes on 256 cores) instead of the first 96")
+                    help="classify EVERY stopped C5 rollout on the host (about three minutes on 256 cores) instead of the first 48")
     ap.add_argument("--closed-loop-rollouts", type=int, default=4096,
                     help="config C5 reported beside the headline number at N=1 (0 = skip)")
     args = ap.parse_args()
@@ -639,7 +639,7 @@ def main():
                       ("open_loop", lambda: open_loop(classify=not args.no_cpu_baseline)),
                       ("config_c3", lambda: config_c3(B, classify=not args.no_cpu_baseline)),
                       ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts, classify=not args.no_cpu_baseline,
-                                                             classify_max=None if args.classify_all else 96)),
+                                                             classify_max=None if args.classify_all else 48)),
                       # the same loop with the three static obstacles only, at the batch size BASELINE.json quotes
                       ("closed_loop_static", lambda: closed_loop_c5(B, n_dyn=0)),
                       # optional extension, NOT reference behaviour (the reference cold-starts): shifted previous plan
