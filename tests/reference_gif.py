@@ -70,3 +70,41 @@ def replay(solver, n_steps):
         if not cl.step():
             break
     return np.cumsum(cl.T_closed), np.asarray(cl.x_closed), cl
+
+
+# ---- every frame of the GIF: the car rectangle (closed-loop pose WITH heading) and the magenta open-loop plan -------------------------
+# (fixture tests/golden/reference_gif_demo9_poses.json, tests/golden/make_gif_pose_fixture.py)
+BOX_XY_TOL = 0.33          # m: two pixels of the GIF (0.163 m each) -- the rectangle is 21 x 9 px, its fit is good to about one
+BOX_THETA_TOL = 0.08       # rad: one pixel across the rectangle's half length (10 px)
+PLAN_POSE_PX = 2.5         # a plan pose of this build must lie within 2.5 px of the frame's magenta ink (a marker's radius) ...
+PLAN_INK_PX = 3.0          # ... and every magenta pixel within 3 px of this build's plan (marker radius + half a pixel of rounding)
+
+
+def pose_fixture():
+    with open(os.path.join(HERE, "golden", "reference_gif_demo9_poses.json")) as f:
+        return json.load(f)
+
+
+def box_errors(pf, xs):
+    """car rectangles of the frames against closed-loop poses xs (n, 3): (distance in m, |heading difference| in rad) per pose"""
+    b = np.asarray(pf["car_box"]["poses"])[:, :3]
+    n = min(len(b), len(xs))
+    d = b[:n] - np.asarray(xs)[:n]
+    return np.hypot(d[:, 0], d[:, 1]), np.abs(d[:, 2])
+
+
+def plan_errors(pf, k, plan):
+    """frame k's magenta ink against this build's plan of solve k, plan (N + 1, 3) -> (largest distance of a plan pose to the ink,
+    largest distance of an ink pixel to the plan's polyline), both in pixels; (nan, nan) for a frame without ink"""
+    runs = pf["plan_ink"]["runs"][k]
+    if not runs:
+        return np.nan, np.nan
+    m = pf["pixel_of_metre"]
+    ink = np.array([[r, c] for r, c0, c1 in runs for c in range(c0, c1 + 1)], float)
+    P = np.stack([m["y0"] - np.asarray(plan)[:, 1] * m["per_metre_y"], m["x0"] + np.asarray(plan)[:, 0] * m["per_metre_x"]], 1)   # row, column
+    d_pose = np.sqrt(((P[:, None, :] - ink[None, :, :]) ** 2).sum(-1)).min(1)
+    a, b = P[:-1], P[1:]
+    ab = b - a
+    t = np.clip(((ink[:, None, :] - a[None]) * ab[None]).sum(-1) / np.maximum((ab * ab).sum(-1), 1e-12)[None], 0.0, 1.0)
+    d_ink = np.sqrt(((ink[:, None, :] - (a[None] + t[..., None] * ab[None])) ** 2).sum(-1)).min(1)
+    return float(d_pose.max()), float(d_ink.max())
