@@ -30,7 +30,8 @@ struct obca_handle {
     int32_t offm[OBCA_MAX_OBST + 1];
     int two_sided;                     // -1: where only the four-wavefront kernels fit (default), 0: never, 1: always
     int64_t lds_pad;          // dev knob OBCA_LDS_PAD: bytes added to the one-wavefront kernels' LDS request (occupancy experiments)
-    int64_t lds_bytes, lds_bytes_mw;   // one-wavefront kernels; four-wavefront kernels (+ the two-sided sweep's storage)
+    int64_t lds_bytes, lds_bytes_mw;   // one-wavefront kernels; four-wavefront kernels (+ the two-sided sweep's storage) -- both incl. the SOC scratch where it lives in LDS
+    int32_t soc_lds, soc_lds_mw;       // its offset there (doubles), 0 = in HBM (csrc/obca_device.h: obca_soc_lds_wave / _mw)
     int64_t lds_bytes_gm, gm_doubles;  // obca_ipm_kernel_gm: its LDS (O(N) blocks only) and its HBM workspace per workgroup
     int32_t inst_off_gm;
     bool gm_ok;
@@ -139,10 +140,15 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     }
     h->lds_bytes = 8 * lds_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off);
     h->lds_bytes_mw = h->lds_bytes + 8 * (OBCA_ZK_DOUBLES(d->N) + OBCA_HYB_DOUBLES(h->R_max));
-    h->wave_ok = !(h->lds_bytes > 160 * 1024 || h->R_max > 384);     // rows live in registers: <= 6 per lane
-    h->mw_ok = !(h->lds_bytes_mw + 64 > 160 * 1024 || h->R_max > 1280); // 256 threads x 3 or 5 rows; 32 B of static LDS
+    h->wave_ok = !(h->lds_bytes + OBCA_LDS_STATIC_BYTES > OBCA_LDS_CU_BYTES || h->R_max > 384);     // rows live in registers: <= 6 per lane
+    h->mw_ok = !(h->lds_bytes_mw + OBCA_LDS_STATIC_BYTES > OBCA_LDS_CU_BYTES || h->R_max > 1280);   // 256 threads x 3 or 5 rows; up to 64 B of static LDS
+    // the second-order correction's scratch joins the LDS request where that costs no occupancy (csrc/obca_device.h)
+    h->soc_lds = h->wave_ok ? obca_soc_lds_wave(d->N, d->n_obs, h->M) : 0;
+    h->soc_lds_mw = h->mw_ok ? obca_soc_lds_mw(d->N, d->n_obs, h->M) : 0;
+    if (h->soc_lds) h->lds_bytes += 8 * obca_soc_doubles(d->N, d->n_obs, h->M);
+    if (h->soc_lds_mw) h->lds_bytes_mw += 8 * obca_soc_doubles(d->N, d->n_obs, h->M);
     h->lds_bytes_gm = 8 * (gm_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off_gm, h->gm_doubles) + OBCA_ZK_DOUBLES(d->N));
-    h->gm_ok = h->lds_bytes_gm + 64 <= 160 * 1024;
+    h->gm_ok = h->lds_bytes_gm + OBCA_LDS_STATIC_BYTES <= OBCA_LDS_CU_BYTES;
     h->gm_ws = nullptr;
     ObcaDeviceGuard guard(d->device);
     if (!guard.ok) { delete h; return OBCA_E_HIP; }
@@ -296,7 +302,7 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
     L.xopt = xopt; L.uopt = uopt; L.ts_opt = ts_opt; L.status = status; L.iters = iters; L.info = info; L.prof = h->prof;
     L.warm_z = h->warm_z; L.warm_use = h->warm_use; L.warm_mu = h->warm_mu;
     L.cert_z = h->cert_z; L.cert_y = h->cert_y;
-    L.soc_ws = h->soc_ws;
+    L.soc_ws = h->soc_ws; L.soc_lds = h->soc_lds;
     auto cpw = [](ObcaWeightsDev& d, const obca_weights& s) {
         // the reference's double loops use Q[i,j] for every (i,j): only the symmetric part matters
         for (int a = 0; a < 3; ++a)
@@ -354,7 +360,7 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
             h->gm_ws = nullptr;
             return OBCA_E_NOMEM;
         }
-        L.inst_off = h->inst_off_gm;
+        L.inst_off = h->inst_off_gm; L.soc_lds = 0;
         L.gm_ws = h->gm_ws; L.gm_stride = h->gm_doubles;
         ObcaLaunch L2 = L;
         if (h->mode == 5 || auto_gm1(h)) { L.two_sided = 0; L2.two_sided = 0; hipLaunchKernelGGL(obca_ipm_kernel_gm1, dim3(B), dim3(64), (size_t)h->lds_bytes_gm, (hipStream_t)hip_stream, L, L2, L2); }
@@ -370,6 +376,7 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     const bool lane = !mw && (h->mode == 2 || !h->wave_ok);
     if (mw || !lane) {
         // the kernels run the further passes of the start ladder (penalty escalation, next starts) themselves, from their own copy of the descriptor
+        if (mw) L.soc_lds = h->soc_lds_mw;
         ObcaLaunch L2 = L;
         if (mw && h->shape_kernel_mw && h->specialise)
             hipLaunchKernelGGL(h->shape_kernel_mw, dim3(B), dim3(256), (size_t)h->lds_bytes_mw, (hipStream_t)hip_stream, L, L2, L2);

@@ -167,6 +167,28 @@ constexpr ObcaShapeSizes obca_shape_sizes(int N, int nO, int M) {
     t += OBCA_INST_DOUBLES;
     return ObcaShapeSizes{n_max, R_max, inst_off, t};
 }
+/* Scratch of the second-order correction: the original direction (n_max + R_max + 2 npair doubles) and the accumulated residuals of
+   the rows (R_max).  Where it costs no occupancy it lives in LDS BEHIND everything else the kernel carves -- the one-wavefront kernels
+   keep as many workgroups per CU as without it (at most four: one wavefront per SIMD at 512 registers), the four-wavefront kernels
+   (one workgroup per CU) take it while the total stays below the CU's 160 KB -- otherwise in HBM (ObcaLaunch.soc_ws, round 1-5: always;
+   measured in round 5 on the headline launch: 5.8 MB of the 8.1 MB written per launch were this scratch).  Offsets in doubles from the
+   start of the dynamic LDS, 0 = HBM.  One definition for the host and the compile-time-shape instantiations. */
+#define OBCA_LDS_CU_BYTES (160 * 1024)
+#define OBCA_LDS_STATIC_BYTES 64              /* static LDS of the solver kernels (ladder state, screen verdict): 32 ... 64 B */
+constexpr long long obca_soc_doubles(int N, int nO, int M) {
+    return obca_even((long long)obca_shape_sizes(N, nO, M).n_max + 2 * (long long)obca_shape_sizes(N, nO, M).R_max + 2 * (long long)(N + 1) * nO);
+}
+constexpr int obca_wgs_per_cu(long long dyn_bytes, int cap) {
+    return (int)(OBCA_LDS_CU_BYTES / (dyn_bytes + OBCA_LDS_STATIC_BYTES)) < cap ? (int)(OBCA_LDS_CU_BYTES / (dyn_bytes + OBCA_LDS_STATIC_BYTES)) : cap;
+}
+constexpr int obca_soc_lds_wave(int N, int nO, int M) {          /* one-wavefront kernels (also inside the fused closed loop) */
+    const long long base = 8 * obca_shape_sizes(N, nO, M).lds_doubles, with = base + 8 * obca_soc_doubles(N, nO, M);
+    return (obca_wgs_per_cu(base, 4) > 0 && obca_wgs_per_cu(with, 4) == obca_wgs_per_cu(base, 4)) ? (int)obca_shape_sizes(N, nO, M).lds_doubles : 0;
+}
+constexpr int obca_soc_lds_mw(int N, int nO, int M) {            /* four-wavefront LDS kernels: behind the two-sided sweep's storage and the fifth row slot */
+    const long long off = obca_shape_sizes(N, nO, M).lds_doubles + OBCA_ZK_DOUBLES(N) + OBCA_HYB_DOUBLES(obca_shape_sizes(N, nO, M).R_max);
+    return 8 * (off + obca_soc_doubles(N, nO, M)) + OBCA_LDS_STATIC_BYTES <= OBCA_LDS_CU_BYTES ? (int)off : 0;
+}
 /* Compile-time-shape instantiations of the one-wavefront kernel: X(N, nO, M).  With the shape known to the compiler every LDS
    offset is an immediate, the stage loops and the index arithmetic (divisions by nO, M, 4 nO, the stage stride) fold, and the
    scalar registers that held ~35 array offsets and the layout are free: measured on C2 29.7 -> 26.5 ms per 8192 solves, every
@@ -226,6 +248,7 @@ struct ObcaParamsDev {
 struct ObcaLaunch {
     int32_t B, N, nO, M, n_max, R_max, inst_off;
     int32_t two_sided;     /* four-wavefront kernels: Riccati sweep cut in two halves run by two wavefronts (obca_set_two_sided_sweep) */
+    int32_t soc_lds;       /* scratch of the second-order correction in LDS: offset in doubles (obca_soc_lds_wave / _mw), 0 = in HBM (soc_ws) */
     int32_t offm[OBCA_MAX_OBST + 1];
     const int32_t* variant;
     const double *x0, *u0, *xref, *A, *b, *Ts, *term;
@@ -267,5 +290,6 @@ int obca_internal_fill_launch(obca_handle* h, const int32_t* variant, int32_t B,
                               const obca_params* p,
                               double* xopt, double* uopt, double* ts_opt, int32_t* status, int32_t* iters,
                               double* info, ObcaLaunch* out, int64_t* lds_bytes, int* wave_ok);
+/* (the descriptor is filled for the one-wavefront kernels: soc_lds = obca_soc_lds_wave, *lds_bytes includes that scratch) */
 
 #endif

@@ -1636,7 +1636,7 @@ template <bool FROM_MEMORY, class T> __device__ __forceinline__ T* uni(T* p) {
 }
 template <bool FROM_MEMORY> __device__ __forceinline__ double uni(double v) { return FROM_MEMORY ? lane_read(v, 0) : v; }
 struct ObcaHead {
-    int32_t B, N, nO, M, n_max, R_max, inst_off, two_sided;
+    int32_t B, N, nO, M, n_max, R_max, inst_off, two_sided, soc_lds;
     const int32_t* variant;
     const double *x0, *u0, *xref, *A, *b, *Ts, *term;
     double *xopt, *uopt, *ts_opt;
@@ -1653,7 +1653,7 @@ typedef const __attribute__((address_space(4))) ObcaLaunch ObcaLaunchConst;   //
 // The problem shape as the body sees it: ShapeAny -- read from the launch descriptor (any shape the kernel's limits allow);
 // ShapeIs<N, nO, M> -- compile-time constants (csrc/obca_device.h: OBCA_SHAPES): same code, same arithmetic, same results,
 // but every LDS offset, loop bound and index division folds.  The host only launches an instantiation for its own shape.
-struct ShapeAny { static constexpr bool fixed = false; static constexpr int N = 0, nO = 0, M = 0, n_max = 0, R_max = 0, inst_off = 0; };
+struct ShapeAny { static constexpr bool fixed = false; static constexpr int N = 0, nO = 0, M = 0, n_max = 0, R_max = 0, inst_off = 0, soc_lds = 0; };
 // FT: the fixed-time variants only (the closed loop's groups with sensed boxes: their layouts have three rows less than the
 // free-time layout the handle sizes for, csrc/obca_rollout.hip)
 template <int N_, int NO_, int M_, bool FT = false>
@@ -1665,9 +1665,11 @@ struct ShapeIs {
 #if OBCA_NT == 64
     static constexpr int RPL = R_max <= 256 ? 4 : R_max <= 320 ? 5 : 6;       // rows per lane, as obca_solve_batch picks _r4 / _r5 / _r6
     static_assert(R_max <= 384, "shape beyond the one-wavefront kernels");
+    static constexpr int soc_lds = obca_soc_lds_wave(N_, NO_, M_);             // scratch of the second-order correction: LDS offset, 0 = HBM
 #else
     static constexpr int RPL = R_max <= 768 ? 3 : -5;                         // four wavefronts: as _mw_r3 / _mw_r5
     static_assert(R_max <= 1280, "shape beyond the four-wavefront LDS kernels");
+    static constexpr int soc_lds = obca_soc_lds_mw(N_, NO_, M_);
 #endif
 };
 
@@ -1679,7 +1681,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     {
         constexpr bool U = FROM_MEMORY;
         A.B = uni<U>(Ain.B); A.N = uni<U>(Ain.N); A.nO = uni<U>(Ain.nO); A.M = uni<U>(Ain.M); A.n_max = uni<U>(Ain.n_max);
-        A.R_max = uni<U>(Ain.R_max); A.inst_off = uni<U>(Ain.inst_off); A.two_sided = uni<U>(Ain.two_sided);
+        A.R_max = uni<U>(Ain.R_max); A.inst_off = uni<U>(Ain.inst_off); A.two_sided = uni<U>(Ain.two_sided); A.soc_lds = uni<U>(Ain.soc_lds);
         A.variant = uni<U>(Ain.variant); A.x0 = uni<U>(Ain.x0); A.u0 = uni<U>(Ain.u0); A.xref = uni<U>(Ain.xref); A.A = uni<U>(Ain.A);
         A.b = uni<U>(Ain.b); A.Ts = uni<U>(Ain.Ts); A.term = uni<U>(Ain.term); A.xopt = uni<U>(Ain.xopt); A.uopt = uni<U>(Ain.uopt);
         A.ts_opt = uni<U>(Ain.ts_opt); A.status = uni<U>(Ain.status); A.iters = uni<U>(Ain.iters); A.info = uni<U>(Ain.info);
@@ -1688,6 +1690,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         A.gm_ws = Ain.gm_ws; A.gm_stride = Ain.gm_stride;
         if constexpr (SHAPE::fixed) {
             A.N = SHAPE::N; A.nO = SHAPE::nO; A.M = SHAPE::M; A.n_max = SHAPE::n_max; A.R_max = SHAPE::R_max; A.inst_off = SHAPE::inst_off;
+            A.soc_lds = SHAPE::soc_lds;
         }
     }
     if (inst >= A.B) return;
@@ -2008,13 +2011,13 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
 #endif
     // IPOPT's second-order correction (max_soc = 4, kappa_soc = 0.99): when the FIRST trial step of a line search is rejected
     // without reducing the constraint violation, up to max_soc corrected steps are tried -- same matrix (same delta_w),
-    // right-hand side from the accumulated residuals c_soc (rotation rows, kept in S.crot) and g_soc (rows, HBM scratch
-    // A.soc_ws) -- before the step length is halved.  A corrected solve is ANOTHER PASS of this iteration loop with
+    // right-hand side from the accumulated residuals c_soc (rotation rows, kept in S.crot) and g_soc (rows, in the scratch
+    // ws_gsoc below: LDS where it fits, else HBM) -- before the step length is halved.  A corrected solve is ANOTHER PASS of this iteration loop with
     // soc_pass set (the error evaluation and the barrier update are skipped, `it` does not advance), so that the one copy
     // of the solve pipeline serves both and no second loop is wrapped around the factorisation: such a loop kept ~130
     // more registers alive in the hot path (measured: 512 B of scratch per lane, 350 MB of HBM traffic per launch).  The
-    // scalars of the interrupted line search wait in LDS (S.lsv), the original direction in the HBM scratch; rare (~1 line
-    // search in 2000 on the C2 workload).
+    // scalars of the interrupted line search wait in LDS (S.lsv), the original direction in the same scratch; ~1 line search in
+    // 2000 on the C2 workload from the x0 start, one solve in six from the window start (round 5's default).
     enum { LS_TH = 0, LS_FOBJ, LS_DW, LS_AZ, LS_DPHI, LS_PHI, LS_AMIN, LS_PWTH, LS_PWDPHI, LS_ALPHA, LS_THOLD };
     bool soc_pass = false, use_soc = false, first_trial = true;
     int soc_it = 0;
@@ -2068,11 +2071,13 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         }
         PROF(1)
         // ---- Newton step with inertia correction -----------------------------------------------------------
-#define ws_dxo (A.soc_ws + (size_t)inst * (A.n_max + 2 * A.R_max + 2 * L.npair))
+        // (in LDS behind everything else where the host found room for it -- csrc/obca_device.h: obca_soc_lds_wave / _mw --, else this
+        // instance's slice of the HBM scratch)
+#define ws_dxo (A.soc_lds ? smem + A.soc_lds : A.soc_ws + (size_t)inst * (A.n_max + 2 * A.R_max + 2 * L.npair))
 #define ws_dyo (ws_dxo + A.n_max)
 #define ws_gsoc (ws_dyo + A.R_max)
 #define ws_dnuo (ws_gsoc + A.R_max)
-        const int max_soc = A.soc_ws ? O.max_soc : 0;
+        const int max_soc = (A.soc_lds || A.soc_ws) ? O.max_soc : 0;
 #pragma unroll
         for (int j = 0; j < W.slots(); ++j) {       // unconditional writes end the live ranges of the last step data,
             W.dy(j) = 0.0; W.iDs(j) = 0.0; W.iDp(j) = 0.0; W.iDn(j) = 0.0; W.rs(j) = 0.0; W.rp(j) = 0.0; W.rn(j) = 0.0;
@@ -2639,8 +2644,11 @@ __device__ __forceinline__ void solve_with_escalation(const ObcaLaunch& A, const
 #if OBCA_NT == 64 && defined(OBCA_TU_SHAPE)
 // A translation unit of compile-time-shape instantiations (csrc/obca_kernel_s*.hip define OBCA_TU_SHAPE(X) as X(N, nO, M) ...
 // and include this file): only those kernels, none of the generic ones.  obca_ipm_kernel_s<N>_<nO>_<M>.
+#ifndef OBCA_SHAPE_KERNEL_ATTR      /* dev knob (tools/build_variant.sh): e.g. __attribute__((amdgpu_waves_per_eu(2, 2))) for a 256-register build */
+#define OBCA_SHAPE_KERNEL_ATTR
+#endif
 #define OBCA_DEFINE_SHAPE_KERNEL(N_, O_, M_)                                                                                   \
-    extern "C" __global__ void __launch_bounds__(64) obca_ipm_kernel_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { \
+    extern "C" __global__ void __launch_bounds__(64) OBCA_SHAPE_KERNEL_ATTR obca_ipm_kernel_s##N_##_##O_##_##M_(ObcaLaunch A, ObcaLaunch A2, ObcaLaunch A3) { \
         using SH = ShapeIs<N_, O_, M_>;                                                                                        \
         solve_with_escalation<SH::RPL, true, true, SH>(A, A2, A3);                                                            \
     }
