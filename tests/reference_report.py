@@ -47,12 +47,17 @@ def gif_demo11():
 # length is inherited -- they pin the fifteen free-time solves before it and the step count.  The fourth lies six
 # free-time solves after the dodge: it measures WHERE the car is when the phase ends, to about 0.05 m.
 DEMO11_TITLE_STEPS = [23, 29, 39, 59]
-# this build: 98.540 s against the title's 98.55 (|d| = 0.0099 s, the car 0.02 m further on than IPOPT's); before the dodge rung
-# of the ladder it was 0.076 s, a whole step late (see tests/test_reference_demo11.py)
-DEMO11_FOURTH_TOL = 0.0105 + 5e-4
-# a marker centre of the recording is known to about 0.15 m; the two runs take the dodge around the first obstacle 0.33 m apart at
-# most, on the same step
-DEMO11_MARKER_MAX, DEMO11_MARKER_MEAN = 0.35, 0.15
+# What this build does NOT reproduce at the reading precision (stated as such: the strict-xfail tests of tests/test_reference_demo11.py
+# and tests/test_gpu_reference_demo11.py fail on these with TIME_TOL / 0.15 m, and say so in every test report):
+#   * the fourth title: 98.540 s here against 98.55 s -- 0.0099 s, 1.8 x the reading precision of a title (0.0055 s); before the
+#     dodge rung of the ladder it was 0.076 s, a whole step late;
+#   * 20 of the 55 markers: 0.16 .. 0.33 m away against a marker accuracy of 0.15 m (all in the dodge around the two boxes, poses 21-51;
+#     the straight part before it, poses 2-20, is within 0.15 m).
+# The two numbers below are REGRESSION GUARDS on that measured state -- not tolerances of the comparison.
+DEMO11_FOURTH_MEASURED = 0.0099
+DEMO11_FOURTH_GUARD = 0.011
+DEMO11_MARKER_ACCURACY = 0.15
+DEMO11_MARKER_GUARD_MAX, DEMO11_MARKER_GUARD_MEAN = 0.35, 0.15
 
 
 def replay(setting, solver, n_steps):

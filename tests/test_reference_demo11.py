@@ -25,20 +25,57 @@ def gif():
     return reference_report.gif_demo11()
 
 
-def check_run(cum, x_closed, fx, gif):
+def run_errors(cum, x_closed, fx, gif):
+    """-> [(step, |title - cumulative time|) x 4], distance of every marker to its pose"""
     titles = sorted(f["spend_time"] for f in fx["figure11_demo11"]["frames"])
     hits = reference_report.match(cum, titles)
-    assert [k for k, _ in hits] == reference_report.DEMO11_TITLE_STEPS, hits
-    assert max(e for _, e in hits[:3]) <= reference_report.TIME_TOL, hits
-    assert hits[3][1] <= reference_report.DEMO11_FOURTH_TOL, hits
     M, first = np.array(gif["markers_xy"]), gif["first_marker_is_pose"]
     X = np.asarray(x_closed)[first:first + len(M), :2]
-    d = np.hypot(*(X - M).T)
-    assert d.max() <= reference_report.DEMO11_MARKER_MAX and d.mean() <= reference_report.DEMO11_MARKER_MEAN, (d.max(), d.mean())
-    assert d[:19].max() <= 0.16                                  # poses 2 .. 20: the straight part, before the first obstacle is met
-    # (poses 21-22: 0.23 / 0.29 m -- the markers overlap there, and the recording's own spacing 23.91 -> 25.04 is more than the
-    # 0.9974 m a step of 1.6623 s at 0.6 m/s allows, so either marker is off by at least 0.13 m)
+    return hits, np.hypot(*(X - M).T)
+
+
+def check_run(cum, x_closed, fx, gif):
+    """what the build DOES show at reading precision: the four steps, three titles, the 19 markers of the straight part -- plus
+    regression guards on the rest (the fourth title, the markers of the dodge), which it does not: see the strict xfails below"""
+    hits, d = run_errors(cum, x_closed, fx, gif)
+    assert [k for k, _ in hits] == reference_report.DEMO11_TITLE_STEPS, hits
+    assert max(e for _, e in hits[:3]) <= reference_report.TIME_TOL, hits
+    assert d[:19].max() <= reference_report.DEMO11_MARKER_ACCURACY + 0.005          # poses 2 .. 20: the straight part, before the first obstacle is met
+    assert hits[3][1] <= reference_report.DEMO11_FOURTH_GUARD, hits                  # guard, not a tolerance (tests/reference_report.py)
+    assert d.max() <= reference_report.DEMO11_MARKER_GUARD_MAX and d.mean() <= reference_report.DEMO11_MARKER_GUARD_MEAN, (d.max(), d.mean())
     return hits, d
+
+
+def check_fourth_title_at_reading_precision(cum, x_closed, fx, gif):
+    hits, _ = run_errors(cum, x_closed, fx, gif)
+    assert hits[3][1] <= reference_report.TIME_TOL, "fourth title of Figure 11: %.4f s off (reading precision %.4f s)" % (hits[3][1], reference_report.TIME_TOL)
+
+
+def check_markers_at_reading_precision(cum, x_closed, fx, gif):
+    """one documented exception: markers 21 and 22 overlap in the recording, whose own spacing there (23.91 -> 25.04 m) is more than
+    the 0.9974 m a step of 1.6623 s at 0.6 m/s allows -- either of them is off by at least 0.13 m in the fixture itself"""
+    _, d = run_errors(cum, x_closed, fx, gif)
+    first = gif["first_marker_is_pose"]
+    keep = np.array([first + i not in (21, 22) for i in range(len(d))])
+    assert d[keep].max() <= reference_report.DEMO11_MARKER_ACCURACY, "markers of the demo11 recording: up to %.2f m off (accuracy 0.15 m), %d of %d beyond it" % (
+        d[keep].max(), int((d[keep] > reference_report.DEMO11_MARKER_ACCURACY).sum()), int(keep.sum()))
+
+
+@pytest.fixture(scope="module")
+def default_run():
+    s = native_build.LpiObca()
+    cum, cl = reference_report.replay(reference_report.demo11_setting(), s, 61)
+    return cum, cl.x_closed
+
+
+@pytest.mark.xfail(strict=True, reason="measured 0.0099 s against the 0.0055 s a title can be read to: the car is 0.02 m further on than IPOPT's when the fixed-time phase ends")
+def test_fourth_title_of_figure_11_at_reading_precision(fx, gif, default_run):
+    check_fourth_title_at_reading_precision(*default_run, fx, gif)
+
+
+@pytest.mark.xfail(strict=True, reason="measured: 18 of 53 markers 0.16-0.33 m from their pose (accuracy 0.15 m) -- the dodge around the two boxes is driven up to 0.33 m beside the reference's")
+def test_markers_of_the_demo11_recording_at_reading_precision(fx, gif, default_run):
+    check_markers_at_reading_precision(*default_run, fx, gif)
 
 
 @pytest.mark.parametrize("engine", ["lpi", "oracle"])

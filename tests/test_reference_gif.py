@@ -104,13 +104,7 @@ def test_step_70_is_the_references_own_local_optimum(fx):
     assert (p.N + 1) * (10 * T_gif + T_gif ** 2) > p.objective(z)
 
 
-def test_demo1_recording_first_twelve_steps():
-    """Second, weaker piece of reference-held evidence: the screen recording ``images/OBCA_dynObs_demo1.gif`` (no numbers, code
-    version and settings of the run unrecorded).  With the checked-in demo1 defaults (N = 6, lidar 10 m; only the stop at k = 30
-    lifted) the first 12 closed-loop poses -- 7 x obca_mpc4, 5 x obca_mpc6 -- lie on the recording's markers (<= 0.06 m; the
-    recording resolves ~0.02 m); in the dodge that follows (steps 13-19) the recorded run turns away from the moving box two
-    steps later than this one (up to 0.9 m apart), after which both rejoin the path (<= 0.25 m) and end on the same poses.
-    Asserted as measured; which of the two plans IPOPT's run owes to an unrecorded setting cannot be told from a recording."""
+def _demo1_run():
     import json
     import os
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
@@ -130,10 +124,35 @@ def test_demo1_recording_first_twelve_steps():
     for _ in range(80):
         if not cl.step():
             break
+    return dots, s, cl
+
+
+@pytest.fixture(scope="module")
+def demo1_run():
+    return _demo1_run()
+
+
+def test_demo1_recording_first_twelve_steps(demo1_run):
+    """Second, weaker piece of reference-held evidence: the screen recording ``images/OBCA_dynObs_demo1.gif`` (no numbers, code
+    version and settings of the run unrecorded).  With the checked-in demo1 defaults (N = 6, lidar 10 m; only the stop at k = 30
+    lifted) the first 12 closed-loop poses -- 7 x obca_mpc4, 5 x obca_mpc6 -- lie on the recording's markers (<= 0.06 m; the
+    recording resolves ~0.02 m), and both runs end on the same poses.  What happens in between is the strict xfail below."""
+    dots, s, cl = demo1_run
     assert cl.goal_reached()
     assert [c["variant"] for c in s.calls][:12] == [4] * 7 + [6] * 5
     xs = np.asarray(cl.x_closed)[:, :2]
     d12 = np.sqrt(((xs[1:13, None, :] - dots[None]) ** 2).sum(-1)).min(1)
     assert d12.max() <= 0.06, d12
     d = np.sqrt(((xs[:, None, :] - dots[None]) ** 2).sum(-1)).min(0)          # every marker: nearest pose of this run
-    assert d.max() <= 1.0 and np.sort(d)[-7] <= 0.25, np.round(d, 2)
+    assert np.sort(d)[-7] <= 0.25, np.round(d, 2)                             # all but the six markers of the dodge
+    assert d.max() <= 1.0                                                     # regression guard on the measured 0.84 m, NOT a tolerance
+
+
+@pytest.mark.xfail(strict=True, reason="measured: in the dodge (steps 13-19) this build turns away from the moving box two steps earlier than the recorded run, "
+                                      "six markers up to 0.84 m from the nearest pose; at step 13 the fixed-time problem has three local optima and IPOPT, "
+                                      "this build's default start and its zero start take three of them (DESIGN.md section 2)")
+def test_demo1_recording_every_marker_at_reading_precision(demo1_run):
+    dots, s, cl = demo1_run
+    xs = np.asarray(cl.x_closed)[:, :2]
+    d = np.sqrt(((xs[:, None, :] - dots[None]) ** 2).sum(-1)).min(0)
+    assert d.max() <= 0.06, "markers of the demo1 recording: up to %.2f m from the nearest pose of this run" % d.max()
