@@ -39,6 +39,12 @@ def test_fixed_time_moving_obstacles_match_dense_oracle():
     _check(sc.make_batch_c3(4, 8, gated=True), 8, 4)
 
 
+def test_config_c3_gated_shape_matches_dense_oracle():
+    """BASELINE configs[2] itself -- N = 20, five obstacles with time-varying rows, obca_mpc6, 1114 rows -- so that the build
+    container sees the structured core against the dense oracle at that shape too (~7 s of one thread per dense solve)"""
+    assert _check(sc.make_batch_c3(4, 20, gated=True), 20, 4) >= 2
+
+
 def test_skipped_instances_are_left_alone():
     b = sc.make_batch(4, 5)
     var = np.array([4, 0, 4, 0], np.int32)

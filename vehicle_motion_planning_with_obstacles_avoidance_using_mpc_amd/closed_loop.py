@@ -37,6 +37,13 @@ class closedLoop:
         except (AttributeError, TypeError, ValueError):
             has_kw = False
         self._mpc6_kw = {"single_start": True} if has_kw else {}
+        # likewise per call: the open-loop plan's reference is start and goal only (mpc_openLoop_freeTime), so that call asks -- where
+        # the solver object offers the keyword -- for the x0 start first
+        try:
+            has_so = "start_order" in inspect.signature(solver.obca_mpc4).parameters
+        except (AttributeError, TypeError, ValueError):
+            has_so = False
+        self._open_loop_kw = {"start_order": "x0"} if has_so else {}
         st = self.setting
         self.path_solver = a_star(st.org_gridMap, (st.startPose[1], st.startPose[0]), (st.goalPose[1], st.goalPose[0]))
         # constants of src/closed_loop.py:32-101
@@ -78,19 +85,15 @@ class closedLoop:
         self.update_obstacle_constraint(self.N_free, self.Ts, 0)
         self.xref = self.update_path(self.N_free, self.x0, self.xF, allAviable=0, type="startGoal_only")
         # the reference of this call is start and goal only -- no trajectory a solve could start from (the default order starts at
-        # the reference window): where the solver object offers the choice and was left at its default, x0 goes first for this call
-        # (the same optimum either way; from the straight line through the obstacles it takes three times the iterations)
-        s = self.obca_solver
-        swap = getattr(s, "start_order", None) == "default"
-        if swap:
-            s.start_order = "x0"
-        try:
-            self.xOpt, self.uOpt, self.feas, self.Ts_opt = s.obca_mpc4(
-                self.Ts, self.P_free, self.Q_free, self.R_free, self.N_free, self.x0, self.xL, self.xU, self.uL, self.uU,
-                self.xref, self.nObs, self.vObs, self.AObs, self.bObs, self.dmin, self.ego, self.u0)
-        finally:
-            if swap:
-                s.start_order = "default"
+        # the reference window): where the solver object offers the keyword, x0 goes first for THIS call unless the object was
+        # told otherwise (the same optimum either way; from the straight line through the obstacles it takes three times the
+        # iterations).  The solver object itself is not touched (re-entrant); one without the keyword runs its own default.
+        kw = dict(self._open_loop_kw)
+        if kw and getattr(self.obca_solver, "start_order", "default") != "default":
+            kw = {}
+        self.xOpt, self.uOpt, self.feas, self.Ts_opt = self.obca_solver.obca_mpc4(
+            self.Ts, self.P_free, self.Q_free, self.R_free, self.N_free, self.x0, self.xL, self.xU, self.uL, self.uU,
+            self.xref, self.nObs, self.vObs, self.AObs, self.bObs, self.dmin, self.ego, self.u0, **kw)
 
     def mpc_openLoop_fixTime(self):
         self.xref = self.xOpt

@@ -172,9 +172,17 @@ extern "C" int obca_rollouts_reset(obca_rollouts* r, const double* start, const 
                                    void* hip_stream) {
     if (!r || !start || !goal || !path || !path_len || !static_A || !static_b || !params || (r->dims.n_dyn > 0 && !dyn))
         return OBCA_E_INVAL;
+    // the parameters are checked BEFORE anything is touched: a refused call leaves the handle as it was (state, descriptors, ready)
+    {
+        ObcaOptsDev probe;
+        if (params->struct_size != (uint32_t)sizeof(obca_params) ||
+            !obca_resolve_starts(&probe, params->start_order, params->single_start, params->patience, params->retry_iter, r->dims.N, params->dodge, params->terminal_screen))
+            return OBCA_E_INVAL;
+    }
     ObcaDeviceGuard guard(r->dims.device);
     if (!guard.ok) return OBCA_E_HIP;
     hipStream_t s = (hipStream_t)hip_stream;
+    r->ready = false;                      // from here on the device state is being rewritten: not usable again until this call has succeeded
     r->queue_ran = false;                  // an aborted work queue of an EARLIER run says nothing about the rollouts started here
     rollout::Dev& D = r->D;
     const size_t B = D.B, N1 = D.Nm + 1, S = D.S, nd = D.n_dyn;

@@ -43,11 +43,12 @@ class obca:
         return self._solvers[key]
 
     def _run(self, variant, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0,
-             terminal_set=None, single_start=False):
+             terminal_set=None, single_start=False, start_order=None):
         m, x0v, u0v, xr, A, b, Tsv, term = pack_reference_call(variant, Ts, N, x0, xref, nObs, vObs, AObs, bObs, u0,
                                                                 terminal_set)
         kw = dict(xL=xL, xU=xU, uL=uL, uU=uU, ego=ego, dmin=dmin)
-        kw.update(start_order=self.start_order, single_start=bool(single_start or self.single_start), dodge=self.dodge, terminal_screen=self.terminal_screen)
+        kw.update(start_order=self.start_order if start_order is None else start_order, single_start=bool(single_start or self.single_start),
+                  dodge=self.dodge, terminal_screen=self.terminal_screen)
         if variant == 4:
             prm = SolverParams(Q_free=Q, R_free=R, P_free=P, **kw)
         else:
@@ -61,8 +62,10 @@ class obca:
         u_Opt = out.uopt[0].cpu().numpy()
         return x_Opt, u_Opt, feas, float(out.ts_opt[0].item())
 
-    def obca_mpc4(self, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0):
-        return self._run(4, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0)
+    def obca_mpc4(self, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, start_order=None):
+        """start_order (not a reference argument): the order of the ladder's starts for THIS call -- for a caller whose reference is
+        no trajectory (the open-loop plan's start-and-goal reference: "x0"); None = the object's ``start_order``"""
+        return self._run(4, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, start_order=start_order)
 
     def obca_mpc6(self, Ts, P, Q, R, N, x0, xL, xU, uL, uU, xref, nObs, vObs, AObs, bObs, dmin, ego, u0, uOpt,
                   terminal_set, single_start=False):
