@@ -128,7 +128,9 @@ enum {
                                           Two exceptions keep x0 first for every variant: single_start = 1 (a caller with its own fallback wants the
                                           start that fails fastest: the closed loop's obca_mpc6 before obca_mpc8) and obca_set_warm_start (the stored
                                           plan stands for x0).  A caller whose reference window is no trajectory (start and goal only: the open-loop
-                                          plan) is served better by OBCA_START_X0_FIRST. */
+                                          plan) is served better by OBCA_START_X0_FIRST: the x0 start then also runs under `patience` instead of the smaller
+                                          `retry_iter` (demo9 at N >= 66 needs 600-1300 iterations from x0) -- the Python mirror's open-loop plan passes it
+                                          per call (closedLoop.mpc_openLoop_freeTime). */
     OBCA_START_WINDOW_FIRST = 1,       /* window -> x0 -> zeros, also for single-start and warm-started calls */
     OBCA_START_ZEROS_FIRST = 2,        /* zeros -> window -> x0: the reference's literal start first (the default of
                                           obca_mpc 0.1)                                            */

@@ -36,6 +36,7 @@ struct obca_handle {
     int32_t inst_off_gm;
     bool gm_ok;
     double* gm_ws;                     // allocated on first use: max_batch slices
+    bool gm_ws_failed;                 // ... and that allocation failed once: auto mode stops choosing the workspace kernels for this handle
     double* prof;
     int mode;                 /* 0 auto, 1 wave-per-instance (LDS), 2 lane-per-instance (HBM workspace), 3 four waves per instance */
     obca_wave_kernel_t shape_kernel;   /* instantiation of the one-wavefront kernel for exactly this shape, or nullptr */
@@ -75,8 +76,12 @@ bool dims_ok(const obca_dims* d) {
 // 187 ... 276 ms against 131 ... 214 ms (the local blocks of five obstacles keep four wavefronts busy); four obstacles / 10 rows per stage,
 // obca_mpc6 / 8, N = 10 ... 20: 140 ... 302 ms against 107 ... 179 ms; three obstacles with the fixed-time variants gain like the free-time
 // one (tools/gpu_gm1_four.py).  Same words as the
-// four-wavefront kernels with the one-sided sweep.  A function of the SHAPE only.
-bool auto_gm1(const obca_handle* h) { return h->mode == 0 && !h->wave_ok && h->gm_ok && h->dims.n_obs <= 3; }
+// four-wavefront kernels with the one-sided sweep.  A function of the SHAPE only -- and only of the MEASURED region (round 6, advisor):
+// horizons up to N = 26 that the four-wavefront LDS kernel could run as well.  Longer horizons and shapes beyond the LDS keep the
+// kernels they had before gm1 existed (four wavefronts: LDS resident where it fits, HBM workspace otherwise) until someone measures
+// them; and a handle whose workspace cannot be allocated falls back to the LDS-resident kernel, which needs none.
+#define OBCA_GM1_MAX_N 26
+bool auto_gm1(const obca_handle* h) { return h->mode == 0 && !h->wave_ok && h->mw_ok && h->gm_ok && h->dims.n_obs <= 3 && h->dims.N <= OBCA_GM1_MAX_N && !h->gm_ws_failed; }
 
 // (the carve-up itself: csrc/obca_device.h: obca_shape_sizes, shared with the kernels)
 int64_t lds_doubles(int N, int nO, int M, int& n_max, int& R_max, int& inst_off) {
@@ -149,7 +154,7 @@ extern "C" int obca_create(const obca_dims* d, obca_handle** out) {
     if (h->soc_lds_mw) h->lds_bytes_mw += 8 * obca_soc_doubles(d->N, d->n_obs, h->M);
     h->lds_bytes_gm = 8 * (gm_doubles(d->N, d->n_obs, h->M, h->n_max, h->R_max, h->inst_off_gm, h->gm_doubles) + OBCA_ZK_DOUBLES(d->N));
     h->gm_ok = h->lds_bytes_gm + OBCA_LDS_STATIC_BYTES <= OBCA_LDS_CU_BYTES;
-    h->gm_ws = nullptr;
+    h->gm_ws = nullptr; h->gm_ws_failed = false;
     ObcaDeviceGuard guard(d->device);
     if (!guard.ok) { delete h; return OBCA_E_HIP; }
     // a kernel whose LDS request the runtime refuses is simply not offered (the lane kernel serves every shape)
@@ -357,8 +362,13 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
         // shapes beyond the LDS: four wavefronts per instance, rows and O(rows) arrays in the handle's HBM workspace
         if (!h->gm_ok) return OBCA_E_LDS;
         if (!h->gm_ws && hipMalloc(&h->gm_ws, sizeof(double) * (size_t)h->gm_doubles * (size_t)h->dims.max_batch) != hipSuccess) {
+            (void)hipGetLastError();
             h->gm_ws = nullptr;
-            return OBCA_E_NOMEM;
+            // auto mode with an LDS-resident alternative: run that instead of failing the call (it needs no workspace); an explicit
+            // mode 4 / 5 and shapes only the workspace kernels hold report the failure
+            if (!(h->mode == 0 && h->mw_ok)) return OBCA_E_NOMEM;
+            h->gm_ws_failed = true;
+            return obca_solve_batch(h, variant, B, x0, u0, xref, A, b, Ts, term, p, xopt, uopt, ts_opt, status, iters, info, hip_stream);
         }
         L.inst_off = h->inst_off_gm; L.soc_lds = 0;
         L.gm_ws = h->gm_ws; L.gm_stride = h->gm_doubles;
