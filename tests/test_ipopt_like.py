@@ -66,20 +66,30 @@ def test_restoration_phase_moves(nlp_golden):
 
 
 def test_first_steps_of_the_references_demo1_run_from_the_references_own_start():
-    """Figure 12's first title (8.77 s after step 5; tests/golden/reference_report_figures.json) by IPOPT's algorithm from the zero
-    start, five chained solves.  The whole table -- demo1: all four titles and the recording's markers to 0.30 m (the product: 0.84 m,
-    because at step 13 IPOPT's obca_mpc6 ends "infeasible problem detected" and obca_mpc8 answers, where the product's ladder solves
-    obca_mpc6); demo9: 67 consecutive GIF steps, then the heading swing the report's state plot shows; demo11: three titles, the
-    fourth 0.14 s off -- is tools/ipopt_like_study.py -> profiles/r06_ipopt_like_study.json (minutes per run)."""
+    """Three chained solves of the reference's demo1 run (Figure 12) by IPOPT's algorithm from the zero start -- and the finding of
+    the whole study (tools/ipopt_like_study.py -> profiles/r06_ipopt_like_study.json, minutes per run): WHICH optimum the method lands
+    in from the zero start depends on roundoff.  At step 4 of this run the free-time problem has two optima IPOPT's method reaches --
+    T 1.6778 s (f 3145.49: the reference's, and the product's) and T 1.8462 s (f 3678.97); the same code took the first with two BLAS
+    threads (then: all four titles of Figure 12 to 0.005 s, the recording's markers to 0.30 m -- the product: 0.84 m -- because at
+    step 13 obca_mpc6 ends "infeasible problem detected" and obca_mpc8 answers, where the product's ladder solves obca_mpc6) and the
+    second with one or eight.  demo9: 67 consecutive GIF steps either way, then a heading swing like the one the report's state
+    plot shows at step 72.  So the oracle pins single solves (above); chained runs it only reproduces up to the first such fork."""
     import json
     import os
     from tests import reference_report
     from tools.ipopt_like_study import IpoptLikeObca
     s = IpoptLikeObca()
-    cum, cl = reference_report.replay(reference_report.demo1_setting(), s, 5)
-    assert abs(cum[4] - 8.77) <= reference_report.TIME_TOL
+    cum, cl = reference_report.replay(reference_report.demo1_setting(), s, 4)
     assert all(c["status"] == 0 for c in s.calls)
+    assert np.allclose(cum[:3], [2.03789, 3.73613, 5.41863], atol=2e-5)
+    assert min(abs(cl.T_closed[3] - 1.6778), abs(cl.T_closed[3] - 1.8462)) <= 2e-4          # one of the two optima
+    from tests import native_build
+    p = native_build.LpiObca()
+    cum_p, _ = reference_report.replay(reference_report.demo1_setting(), p, 4)
+    assert np.allclose(cum_p[:3], cum[:3], atol=1e-5) and abs(cum_p[3] - cum_p[2] - 1.6778) <= 2e-4   # the product: the same three steps, then the reference's optimum
     with open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r06_ipopt_like_study.json")) as f:
         study = json.load(f)
-    assert np.allclose(study["demo1"]["Ts_opt"][:5], cl.T_closed, atol=1e-4)      # the committed table is this code's output
-    assert study["demo1"]["distance_s"] == [0.0017, 0.0048, 0.0034, 0.0005] and study["demo9"]["consecutive_steps_matched"] == 67
+    one, two = study["one_blas_thread"], study["two_blas_threads"]
+    assert np.allclose(one["demo1"]["Ts_opt"][:4], cl.T_closed, atol=1e-4)                  # the committed table is this code's output
+    assert one["demo9"]["consecutive_steps_matched"] == two["demo9"]["consecutive_steps_matched"] == 67
+    assert two["demo1"]["distance_s"] == [0.0017, 0.0048, 0.0034, 0.0005] and max(one["demo1"]["distance_s"]) > 0.1
