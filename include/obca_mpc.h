@@ -73,9 +73,12 @@ typedef struct obca_params {
     /* The starts of a solve ("start ladder"; rule and measurements: oracle/ipm_dense.py:solve).  A solve
        that ends without a feasible point -- status 2, -1, -2, -3 -- is repeated from the next start of the order, inside the
        same launch, until one start ends feasible or the order is exhausted; iteration and factorisation counts returned are
-       those of the whole sequence; status and iterate are those of the pass that ended feasible, otherwise those of the LAST pass
-       of the order (so after an exhausted ladder status -1 means "the last start hit its limit retry_iter", not that the first
-       one did; a first start that converged to an infeasible stationary point, status 2, is not reported).  The three starts:
+       those of the whole sequence; status, iterate and info[0..2] are those of the pass that ended feasible.  After an exhausted
+       ladder (obca_mpc 0.6; before: the last pass's, whatever it was) they are those of the most informative pass: the FIRST
+       one, replaced by a later one only if that one converged to a stationary point of the penalty problem with elastic
+       variables left (status 2 -- a statement about the problem) where the held one did not (-1, -2, -3 -- statements about the
+       solver), or if it is the same start's repetition with a raised penalty.  So status 2 after an exhausted ladder means
+       "some start converged and found no feasible point", -1 / -2 / -3 that none converged.  The three starts:
          x0      every variable 0, Topt = 1 as the reference (src/obca.py:856), every pose at x0 -- the iterate IPOPT's first
                  Newton step reaches from the reference's all-zero start (the initial condition and the dynamics linearised
                  at v = 0 read x_k = x0); uses nothing but x0, like the reference's cold start
@@ -103,8 +106,8 @@ typedef struct obca_params {
                                                    start from the window moved 3 m to the right and to the left of the direction of
                                                    travel (ramped in over three stages; lambda, mu on the separating half-space);
                                                    both run, the feasible answer with the lower objective is returned; their
-                                                   iterations are added to `iters`.  A failed rung leaves the answer of the order's
-                                                   last pass.                                                  */
+                                                   iterations are added to `iters`.  A failed rung leaves the answer the order's
+                                                   starts left (see above).                                    */
     int32_t terminal_screen;           /* [on]    0 = the default (on), negative = off.  obca_mpc6 whose terminal set
                                                    x_N >= term[0] no trajectory can reach -- the first step's heading is x0's, the
                                                    speeds are bounded by uL / uU and, from u0, by the acceleration rows; margin for
@@ -379,7 +382,8 @@ int obca_rasterise_batch(const double* boxes, int32_t B, int32_t K, double resol
                          uint8_t* grid, void* hip_stream);
 
 const char* obca_strerror(int code);
-/* "obca_mpc 0.5 (gfx950)": 0.5 = obca_params.struct_size (first member; obca_params_init), the dodge rung and the terminal-set screen,
+/* "obca_mpc 0.6 (gfx950)": 0.6 = the answer of an exhausted start ladder is the most informative pass's (obca_params: the starts of a
+ * solve), the second-order correction's scratch in LDS where it costs no occupancy; 0.5 = obca_params.struct_size (first member; obca_params_init), the dodge rung and the terminal-set screen,
  * OBCA_START_DEFAULT = the window first for obca_mpc4 too, kernel mode 5;
  * 0.2 = the start ladder (start_order / single_start / patience / retry_iter replace restart); 0.3 = second
  * level of the penalty escalation, compile-time-shape instantiations, obca_rollouts_queue_mode; 0.4 = OBCA_START_DEFAULT per variant

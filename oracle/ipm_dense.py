@@ -347,16 +347,27 @@ def solve(p, opts=None, trace=None):
             return _solve_once(p, dict(o, mu_init=RESTART_MU, max_iter=min(max_v, ret)), trace, x_start=dodge_start(p, -1.0 if kind == KIND_DODGE_R else 1.0))
         return _solve_once(p, o, trace, x_start=x0_start(p) if kind == KIND_X0 else None)
 
-    r = None
+    # WHICH pass's answer an exhausted ladder returns (status, iterate, objective; round 6 -- until then: the last pass's): a pass
+    # that ends at a feasible point always; otherwise the first one, replaced by a later one only if that one CONVERGED
+    # (STATUS_INFEASIBLE: a stationary point of the penalty problem with elastic variables left -- a statement about the problem)
+    # where the held one did not (iteration limit, line-search failure: a statement about the solver), or if it is the same
+    # start's repetition with a raised penalty (the sharper statement of the same kind).  Iteration counts: the whole sequence.
+    r = held = None
+    it = nf = 0
     for s, kind in enumerate(kinds):
         if r is not None and r.status in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS):
             break
-        r_new = run(s, kind, rho0)
-        r = r_new if r is None else _accumulate(r_new, r)
-        for mult in RHO_ESCALATION:
-            if r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation"):
-                r = _accumulate(run(s, kind, rho0 * mult), r)
-        r.starts_used = s + 1
+        for level in range(1 + len(RHO_ESCALATION)):
+            if level > 0 and not (r.status == STATUS_INFEASIBLE and p.variant == 4 and not opts.get("no_escalation")):
+                break
+            r = run(s, kind, rho0 * (RHO_ESCALATION[level - 1] if level else 1.0))
+            it, nf = it + r.iters, nf + getattr(r, "nfact", 0)
+            r.start_index = s
+            if _replaces(r, held):
+                held = r
+        starts_used = s + 1
+    r = held
+    r.iters, r.nfact, r.starts_used = it, nf, starts_used
     r.restarted = r.starts_used > 1
     # the dodge rung: fixed-time problems only, after the order is exhausted; both sides run, the feasible answer with the lower
     # objective stays (a failed rung leaves the answer of the order's last pass, with the iterations added)
@@ -378,10 +389,11 @@ def solve(p, opts=None, trace=None):
     return r
 
 
-def _accumulate(r_new, r_old):
-    r_new.iters += r_old.iters
-    r_new.nfact = getattr(r_new, "nfact", 0) + getattr(r_old, "nfact", 0)
-    return r_new
+def _replaces(new, held):
+    """the rule of solve(): does the pass `new` take the place of the answer `held` (csrc/obca_device.h: OBCA_LADDER_REPLACES)"""
+    if held is None or new.status in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS):
+        return True
+    return new.status == STATUS_INFEASIBLE and (held.status != STATUS_INFEASIBLE or held.start_index == new.start_index)
 
 
 def _solve_once(p, opts=None, trace=None, x_start=None):

@@ -958,19 +958,36 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
                 continue;
             }
         }
-        for (int s = 0; s < nstarts; ++s) {
-            if (s > 0 && (status[q] == ST_OK || status[q] == ST_ACCEPTABLE || status[q] == ST_BAD_BOUNDS)) break;
-            const int kind = START_ORDERS[order][s];
-            const int cap = nstarts == 1 ? max_iter_v : (s == 0 ? pat : ret);
-            const double mu0 = kind == KIND_WINDOW ? RESTART_MU : MU_INIT;
-            status[q] = solve_one(&p, &o, xo, uo, ts_opt + q, iters + q, io, kind, mu0, cap);
-            it_sum += iters[q]; if (io) nf_sum += io[3];
-            for (int level = 1; level <= 2 && status[q] == ST_INFEASIBLE && p.variant == 4; ++level) {
-                Opts o2 = o;
-                o2.rho = o.rho * (level == 1 ? 100.0 : 1000.0);         /* csrc/obca_device.h: OBCA_RHO_ESCALATION */
-                status[q] = solve_one(&p, &o2, xo, uo, ts_opt + q, iters + q, io, kind, mu0, cap);
-                it_sum += iters[q]; if (io) nf_sum += io[3];
+        /* which pass's answer an exhausted ladder returns (oracle/ipm_dense.py: _replaces): a feasible one always; otherwise the
+           first, replaced only by a later pass that converged ("infeasible") where the held one did not, or by the same start's
+           repetition with a raised penalty */
+        {
+            double* xp_ = (double*)malloc(sizeof(double) * (3 * (N + 1) + 2 * N));
+            double* up_ = xp_ + 3 * (N + 1);
+            int last = ST_MAXITER, held = 0, held_start = -1;
+            for (int s = 0; s < nstarts && xp_; ++s) {
+                if (s > 0 && (last == ST_OK || last == ST_ACCEPTABLE || last == ST_BAD_BOUNDS)) break;
+                const int kind = START_ORDERS[order][s];
+                const int cap = nstarts == 1 ? max_iter_v : (s == 0 ? pat : ret);
+                const double mu0 = kind == KIND_WINDOW ? RESTART_MU : MU_INIT;
+                for (int level = 0; level <= 2; ++level) {
+                    if (level > 0 && !(last == ST_INFEASIBLE && p.variant == 4)) break;
+                    Opts o2 = o;
+                    if (level) o2.rho = o.rho * (level == 1 ? 100.0 : 1000.0);         /* csrc/obca_device.h: OBCA_RHO_ESCALATION */
+                    double tst, inf_[4];
+                    int itr;
+                    last = solve_one(&p, &o2, xp_, up_, &tst, &itr, inf_, kind, mu0, cap);
+                    it_sum += itr; nf_sum += inf_[3];
+                    const int good = last == ST_OK || last == ST_ACCEPTABLE || last == ST_BAD_BOUNDS;
+                    if (!held || good || (last == ST_INFEASIBLE && (status[q] != ST_INFEASIBLE || held_start == s))) {
+                        memcpy(xo, xp_, sizeof(double) * 3 * (N + 1)); memcpy(uo, up_, sizeof(double) * 2 * N);
+                        ts_opt[q] = tst; status[q] = last;
+                        if (io) { io[0] = inf_[0]; io[1] = inf_[1]; io[2] = inf_[2]; }
+                        held = 1; held_start = s;
+                    }
+                }
             }
+            free(xp_);
         }
         /* the dodge rung (oracle/ipm_dense.py:solve): fixed-time problems after the order is exhausted; both sides run, the
            feasible answer with the lower objective stays */

@@ -182,3 +182,44 @@ def test_out_of_range_start_fields_are_rejected_by_every_cpu_implementation(nlp_
             native_build.lpi_solve(*_packed(case, **bad))
     with pytest.raises(KeyError):
         ipm_dense.solve(build(case), dict(start_order=7))
+
+
+@pytest.mark.parametrize("order,first,second", [("default", "window", "x0"), ("x0", "x0", "window"), ("zeros", "zeros", "window")])
+def test_an_exhausted_ladder_returns_the_most_informative_pass(nlp_golden, order, first, second):
+    """Which pass's status / iterate an exhausted ladder returns (csrc/obca_device.h: OBCA_LADDER_REPLACES; until round 6: the last
+    pass's, whatever it was).  demo1 at N = 5 has no feasible point and every start converges there with elastic
+    variables left, so:
+      * all passes converge: the answer is the FIRST start's (its last penalty level) -- the same words as that start run alone;
+      * the first start cut off after 20 iterations (MAXITER), the second converges: the second's answer, status 2 -- 'no feasible
+        point' says more than 'ran out of iterations';
+      * the first converges, the later ones are cut off: the first's answer stays (before: status -1, the last pass's iterate).
+    Same rule, same words in the numpy specification, the C oracle and the structured core."""
+    case = [c for c in nlp_golden if c["name"] == "demo1_N5_mpc4_step0"][0]
+    p = build(case)
+    engines = (c_oracle.solve_batch, native_build.lpi_solve)
+    alone = {k: [e(*_packed(case, start_order=k, single_start=1)) for e in engines] for k in (first, second)}
+    spec_alone = {k: ipm_dense.solve(p, dict(start_order=k, single_start=True)) for k in (first, second)}
+    assert all(o["status"][0] == 2 for k in alone for o in alone[k])
+
+    def same(o, ref, status=2):
+        assert o["status"][0] == status
+        assert np.array_equal(o["xopt"], ref["xopt"]) and np.array_equal(o["uopt"], ref["uopt"]) and np.array_equal(o["ts_opt"], ref["ts_opt"])
+        assert np.array_equal(o["info"][0, :3], ref["info"][0, :3])
+
+    for i, e in enumerate(engines):
+        full = e(*_packed(case, start_order=order))
+        same(full, alone[first][i])
+        assert full["iters"][0] > alone[first][i]["iters"][0]                    # ... the count is the whole sequence's
+        cut = e(*_packed(case, start_order=order, patience=20))
+        assert cut["iters"][0] > 20
+        # (the second start's passes run under retry_iter = 350 here, under max_iter alone: it converges well below either)
+        same(cut, alone[second][i])
+        late = e(*_packed(case, start_order=order, retry_iter=10))
+        same(late, alone[first][i])
+        assert late["iters"][0] <= alone[first][i]["iters"][0] + 2 * 3 * 11
+    r = ipm_dense.solve(p, dict(start_order=order))
+    assert r.status == 2 and np.array_equal(r.xopt, spec_alone[first].xopt) and r.start_index == 0
+    r = ipm_dense.solve(p, dict(start_order=order, patience=20))
+    assert r.status == 2 and np.array_equal(r.xopt, spec_alone[second].xopt) and r.start_index == 1
+    r = ipm_dense.solve(p, dict(start_order=order, retry_iter=10))
+    assert r.status == 2 and np.array_equal(r.xopt, spec_alone[first].xopt) and r.start_index == 0

@@ -427,7 +427,7 @@ extern "C" const char* obca_strerror(int code) {
     }
 }
 
-extern "C" const char* obca_version(void) { return "obca_mpc 0.5 (gfx950)"; }
+extern "C" const char* obca_version(void) { return "obca_mpc 0.6 (gfx950)"; }
 extern "C" void obca_params_init(obca_params* p) {
     if (!p) return;
     memset(p, 0, sizeof(*p));

@@ -116,6 +116,14 @@
    same start with the next penalty of the escalation; the next start begins at the base penalty again). */
 #define OBCA_MAX_PASSES (3 * (1 + OBCA_N_ESCALATIONS))
 #define OBCA_WINDOW_SPEED_FRAC 0.9
+/* WHICH pass's answer an exhausted ladder leaves in the caller's buffers -- status, iterate, objective (round 6; until then: the last
+   pass's; rule: oracle/ipm_dense.py:_replaces).  A pass that ends at a feasible point always; otherwise the first one, replaced by a
+   later one only if that one CONVERGED (status 2: a stationary point of the penalty problem with elastic variables left -- a statement
+   about the problem) where the held one did not (iteration limit, line-search failure, filter full: statements about the solver), or
+   if it is the same start's repetition with a raised penalty.  The iteration count stays that of the whole sequence. */
+#define OBCA_LADDER_REPLACES(st, start, have, held_st, held_start) \
+    (!(have) || (st) == OBCA_STATUS_OK || (st) == OBCA_STATUS_ACCEPTABLE || (st) == OBCA_STATUS_BAD_BOUNDS || \
+     ((st) == OBCA_STATUS_INFEASIBLE && ((held_st) != OBCA_STATUS_INFEASIBLE || (held_start) == (start))))
 
 /* Line-search filter capacity: a function of the problem SHAPE only, so that every kernel that can run a shape stops at the
    same point when the filter fills up (status OBCA_STATUS_NUMERIC, answered by the next start of the ladder): 64 entries for

@@ -1722,16 +1722,20 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     // OBCA_KIND_DODGE_R / _L): two more passes, BOTH run, the feasible answer with the lower objective stays in the caller's buffers.
     // Between the two a feasible first answer is marked by the transient status OBCA_STATUS_DODGE_OK / _ACC (never seen by a
     // caller: the second pass always replaces it), which the pass loops treat as "go on".
-    __shared__ int ladder_state[4];      // [0] escalation level of the current start (0: base penalty), [1] iterations, [2] factorisations so far, [3] index of the current start (nstarts, nstarts + 1: the dodge passes)
+    // WHICH pass's answer stays in the caller's buffers when no start ends at a feasible point: csrc/obca_device.h: OBCA_LADDER_REPLACES.
+    // The status word in HBM is therefore that of the HELD answer; how the LAST pass ended -- what the ladder's next move depends on --
+    // is a bit of ladder_state[0].
+    __shared__ int ladder_state[4];      // [0] bits 0-3: escalation level of the current start (0: base penalty), bit 4: the last pass converged with elastic variables left, bit 5: an answer is held, bits 8-11: 1 + the start whose converged-infeasible answer is held (0: the held one did not converge); [1] iterations, [2] factorisations so far, [3] index of the current start (nstarts, nstarts + 1: the dodge passes)
     __shared__ double ladder_f;          // objective of a feasible first dodge pass
     const int order = OBCA_EFFECTIVE_ORDER(Ain.prm.opt.order, A.variant[inst], A.warm_z != nullptr && (A.warm_use == nullptr || A.warm_use[inst] != 0), Ain.prm.opt.nstarts == 1);
-    int start_s = 0, escalated = 0;
+    int start_s = 0, escalated = 0, held_bits = 0;
     if (!first) {
         const int st0 = __builtin_amdgcn_readfirstlane(A.status[inst]);     // wave-uniform: the flags below stay scalar
         if (st0 == OBCA_STATUS_OK || st0 == OBCA_STATUS_ACCEPTABLE || st0 < OBCA_STATUS_NUMERIC) return;
-        escalated = __builtin_amdgcn_readfirstlane(ladder_state[0]);
+        const int l0 = __builtin_amdgcn_readfirstlane(ladder_state[0]);
+        escalated = l0 & 15; held_bits = l0 & 0xf20;
         start_s = __builtin_amdgcn_readfirstlane(ladder_state[3]);
-        if (A.variant[inst] == 4 && st0 == OBCA_STATUS_INFEASIBLE && escalated < OBCA_N_ESCALATIONS) ++escalated;
+        if (A.variant[inst] == 4 && (l0 & 16) && escalated < OBCA_N_ESCALATIONS) ++escalated;
         else { escalated = 0; if (++start_s >= Ain.prm.opt.nstarts + ((Ain.prm.opt.dodge && A.variant[inst] != 4) ? 2 : 0)) return; }
     }
     const double rho_mult = escalated ? OBCA_RHO_ESCALATION(escalated) : 1.0;
@@ -1857,7 +1861,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         if (lane == 0) {
             in.Tmax = dis / (L.N * in.uU[0] * in.Ts) + 1.0;
             // (every thread read the ladder's state before the barriers above)
-            ladder_state[0] = escalated; ladder_state[3] = start_s;
+            ladder_state[0] = escalated | held_bits; ladder_state[3] = start_s;
             if (first) { ladder_state[1] = 0; ladder_state[2] = 0; }
         }
     }
@@ -2447,6 +2451,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     if (A.prof && lane == 0) for (int i = 0; i < 20; ++i) A.prof[(size_t)inst * 20 + i] = (double)prof_t[i];
 #endif
 
+    const int l0 = __builtin_amdgcn_readfirstlane(ladder_state[0]);      // (read by every wavefront BEFORE the barrier, rewritten by thread 0 after it)
     SYNC();
     if ((status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE) && GET(IV_EMAX) > O.feas_tol)
         status = OBCA_STATUS_INFEASIBLE;
@@ -2466,7 +2471,12 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     int status_out = status;
     {
         const int ls = __builtin_amdgcn_readfirstlane(ladder_state[3]), nst = Ain.prm.opt.nstarts;
-        if (ls >= nst) {
+        if (ls < nst) {                // a start of the order: OBCA_LADDER_REPLACES
+            const int held_code = (l0 >> 8) & 15;
+            keep = OBCA_LADDER_REPLACES(status, ls + 1, l0 & 32, held_code ? OBCA_STATUS_INFEASIBLE : OBCA_STATUS_MAXITER, held_code);
+            if (!keep) status_out = -100;
+            if (lane == 0) ladder_state[0] = (l0 & 15) | (status == OBCA_STATUS_INFEASIBLE ? 16 : 0) | 32 | ((keep ? (status == OBCA_STATUS_INFEASIBLE ? ls + 1 : 0) : held_code) << 8);
+        } else {
             const bool ok = status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE;
             if (ls == nst) {           // to the right: goes out if feasible, marked "one more pass to come"
                 keep = ok;

@@ -1557,24 +1557,6 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     Out o;
     o.status = OBCA_STATUS_MAXITER;
     int iters = 0, nfact = 0;
-    for (int s = 0; s < O0.nstarts; ++s) {
-        if (s > 0 && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) break;
-        const int order = OBCA_EFFECTIVE_ORDER(O0.order, L.variant, warm, O0.nstarts == 1);
-        const int kind = OBCA_START_KIND(order, s);
-        const int cap = O0.nstarts == 1 ? max_iter_v : (s == 0 ? O0.patience : O0.retry_iter);
-        const bool use_warm = warm && kind == OBCA_WARM_KIND(order);
-        const double* z = use_warm ? A.warm_z + inst * (size_t)A.n_max : nullptr;
-        const double mu0 = use_warm ? A.warm_mu : (kind == OBCA_KIND_WINDOW ? OBCA_RESTART_MU : OBCA_MU_INIT);
-        o = solve_instance(L, S, in, O0, z, mu0, kind, cap);
-        iters += o.iters; nfact += o.nfact;
-        for (int level = 1; level <= OBCA_N_ESCALATIONS && o.status == OBCA_STATUS_INFEASIBLE && L.free_T; ++level) {
-            // the l1 penalty is exact only while rho exceeds the multipliers: "rho too small" looks like "infeasible"
-            ObcaOptsDev O = O0;
-            O.rho *= OBCA_RHO_ESCALATION(level);
-            o = solve_instance(L, S, in, O, z, mu0, kind, cap);
-            iters += o.iters; nfact += o.nfact;
-        }
-    }
     // what a pass leaves behind goes to the caller's buffers
     auto store = [&](const Out& r) {
         if (A.warm_z != nullptr && (r.status == OBCA_STATUS_OK || r.status == OBCA_STATUS_ACCEPTABLE)) {
@@ -1602,18 +1584,38 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
             io[0] = r.f; io[1] = r.elastic; io[2] = r.E0;
         }
     };
-    store(o);
+    // (which pass's answer stays there when no start ends at a feasible point: csrc/obca_device.h: OBCA_LADDER_REPLACES)
+    bool have = false;
+    int held_st = OBCA_STATUS_MAXITER, held_start = -1;
+    for (int s = 0; s < O0.nstarts; ++s) {
+        if (s > 0 && (o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) break;
+        const int order = OBCA_EFFECTIVE_ORDER(O0.order, L.variant, warm, O0.nstarts == 1);
+        const int kind = OBCA_START_KIND(order, s);
+        const int cap = O0.nstarts == 1 ? max_iter_v : (s == 0 ? O0.patience : O0.retry_iter);
+        const bool use_warm = warm && kind == OBCA_WARM_KIND(order);
+        const double* z = use_warm ? A.warm_z + inst * (size_t)A.n_max : nullptr;
+        const double mu0 = use_warm ? A.warm_mu : (kind == OBCA_KIND_WINDOW ? OBCA_RESTART_MU : OBCA_MU_INIT);
+        for (int level = 0; level <= OBCA_N_ESCALATIONS; ++level) {
+            // the l1 penalty is exact only while rho exceeds the multipliers: "rho too small" looks like "infeasible"
+            if (level > 0 && !(o.status == OBCA_STATUS_INFEASIBLE && L.free_T)) break;
+            ObcaOptsDev O = O0;
+            if (level) O.rho *= OBCA_RHO_ESCALATION(level);
+            o = solve_instance(L, S, in, O, z, mu0, kind, cap);
+            iters += o.iters; nfact += o.nfact;
+            if (OBCA_LADDER_REPLACES(o.status, s, have, held_st, held_start)) { store(o); have = true; held_st = o.status; held_start = s; }
+        }
+    }
     // The dodge rung (csrc/obca_device.h: OBCA_KIND_DODGE_*): fixed-time problems on which every start of the order ended
     // without a feasible point -- the window moved to the right, then to the left; both run, the feasible answer with the lower
     // objective is the one that stays in the caller's buffers (the first pass's outputs are overwritten only by a better one)
     if (O0.dodge && !L.free_T && shortfall < -OBCA_DODGE_MIN_SPARE && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
-        bool have = false;
+        bool dodged = false;
         double fbest = 0.0;
         for (int side = 0; side < 2; ++side) {
             const Out r = solve_instance(L, S, in, O0, nullptr, OBCA_RESTART_MU, side == 0 ? OBCA_KIND_DODGE_R : OBCA_KIND_DODGE_L, O0.retry_iter);
             iters += r.iters; nfact += r.nfact;
             const bool ok = r.status == OBCA_STATUS_OK || r.status == OBCA_STATUS_ACCEPTABLE;
-            if (ok && (!have || r.f < fbest)) { store(r); have = true; fbest = r.f; }
+            if (ok && (!dodged || r.f < fbest)) { store(r); dodged = true; fbest = r.f; }
         }
     }
     A.iters[inst] = iters;
