@@ -139,6 +139,13 @@ KIND_DODGE_R, KIND_DODGE_L = 3, 4
 DODGE_OFFSET = 3.0
 DODGE_RAMP = 3
 DODGE_MIN_SPARE = 0.1          # obca_mpc6: metres of reach beyond the terminal set below which the rung is not tried (OBCA_DODGE_MIN_SPARE)
+# second level of the rung (round 6; obca_mpc8 only -- the variant with no fallback behind it: where it fails the reference's closed loop
+# stops, src/closed_loop.py:401-413): the same two starts with IPOPT's own initial barrier parameter (mu_init 0.1) instead of
+# RESTART_MU.  The dodge starts are nearly feasible, with active rows; a barrier parameter of 1 pushes the first iterates far enough
+# from them to fall back into the basin of the infeasible stationary point.  Seen on C5 world 667 (step 20), then on the only two solver
+# failures of 8192 worlds no rule was looked at on (7225, 11188: profiles/r06_c5_heldout_failures.json): all three end feasible.
+KIND_DODGE_R2, KIND_DODGE_L2 = 5, 6
+DODGE_LEVEL2_MU = 0.1
 
 
 def retry_iter(N):
@@ -343,8 +350,9 @@ def solve(p, opts=None, trace=None):
         o = dict(opts, rho=rho, max_iter=cap)
         if kind == KIND_WINDOW:
             return _solve_once(p, dict(o, mu_init=RESTART_MU), trace, x_start=window_start(p))
-        if kind in (KIND_DODGE_R, KIND_DODGE_L):
-            return _solve_once(p, dict(o, mu_init=RESTART_MU, max_iter=min(max_v, ret)), trace, x_start=dodge_start(p, -1.0 if kind == KIND_DODGE_R else 1.0))
+        if kind in (KIND_DODGE_R, KIND_DODGE_L, KIND_DODGE_R2, KIND_DODGE_L2):
+            return _solve_once(p, dict(o, mu_init=RESTART_MU if kind <= KIND_DODGE_L else DODGE_LEVEL2_MU, max_iter=min(max_v, ret)), trace,
+                               x_start=dodge_start(p, -1.0 if kind in (KIND_DODGE_R, KIND_DODGE_R2) else 1.0))
         return _solve_once(p, o, trace, x_start=x0_start(p) if kind == KIND_X0 else None)
 
     # WHICH pass's answer an exhausted ladder returns (status, iterate, objective; round 6 -- until then: the last pass's): a pass
@@ -377,11 +385,14 @@ def solve(p, opts=None, trace=None):
     if p.variant != 4 and opts.get("dodge", True) and short < -DODGE_MIN_SPARE and r.status not in (STATUS_OK, STATUS_ACCEPTABLE, STATUS_BAD_BOUNDS):
         best = None
         it, nf = r.iters, getattr(r, "nfact", 0)
-        for kind in (KIND_DODGE_R, KIND_DODGE_L):
-            d = run(1, kind, rho0)
-            it, nf = it + d.iters, nf + getattr(d, "nfact", 0)
-            if d.status in (STATUS_OK, STATUS_ACCEPTABLE) and (best is None or d.f < best.f):
-                best = d
+        for level in ((KIND_DODGE_R, KIND_DODGE_L), (KIND_DODGE_R2, KIND_DODGE_L2)):
+            if best is not None or (level[0] == KIND_DODGE_R2 and p.variant != 8):
+                break
+            for kind in level:
+                d = run(1, kind, rho0)
+                it, nf = it + d.iters, nf + getattr(d, "nfact", 0)
+                if d.status in (STATUS_OK, STATUS_ACCEPTABLE) and (best is None or d.f < best.f):
+                    best = d
         if best is not None:
             best.starts_used, best.restarted = r.starts_used, True
             r = best

@@ -996,10 +996,13 @@ int obca_oracle_solve_batch(int N, int n_obs, const int* m, const int* variant, 
             double* ut_ = xt_ + 3 * (N + 1);
             int have = 0;
             double fbest = 0.0;
-            for (int side = 0; side < 2 && xt_; ++side) {
+            /* second level (obca_mpc8 only, oracle/ipm_dense.py: DODGE_LEVEL2_MU): the same two starts at IPOPT's own mu_init, if the first level found nothing */
+            for (int pass = 0; pass < (p.variant == 8 ? 4 : 2) && xt_; ++pass) {
+                if (pass == 2 && have) break;
+                const int side = pass & 1;
                 double tst, inf_[4];
                 int itr;
-                const int st = solve_one(&p, &o, xt_, ut_, &tst, &itr, inf_, side == 0 ? KIND_DODGE_R : KIND_DODGE_L, RESTART_MU, ret);
+                const int st = solve_one(&p, &o, xt_, ut_, &tst, &itr, inf_, side == 0 ? KIND_DODGE_R : KIND_DODGE_L, pass < 2 ? RESTART_MU : MU_INIT, ret);
                 it_sum += itr; nf_sum += inf_[3];
                 if ((st == ST_OK || st == ST_ACCEPTABLE) && (!have || inf_[0] < fbest)) {
                     memcpy(xo, xt_, sizeof(double) * 3 * (N + 1)); memcpy(uo, ut_, sizeof(double) * 2 * N);

@@ -89,11 +89,38 @@ def test_two_stage_open_loop_planner(demo, n_free, n_fix):
     assert kkt_check.min_clearance(out.xopt[0].cpu().numpy(), EGO, call["m"], call["A"], call["b"]) >= DMIN - 1e-6
 
 
-_STAGE_COST = {}          # seconds per (iteration x stage) of the first parametrisation (demo1, N = 10), this box
+# absolute ceilings beside the self-relative bounds below (a uniformly slower build must not pass): warm solve of one instance, seconds;
+# measured 0.02 (N = 10) ... 0.45 (demo9, N = 74), the reference 3.69 s / 136.7 s
+ABS_CEILING_S = {10: 0.3, 40: 0.6, 50: 1.0, 66: 1.5, 74: 1.5}
+
+
+@pytest.fixture(scope="module")
+def stage_cost_ref():
+    """seconds per (iteration x stage) of the shortest horizon (demo1, N = 10, one-CU kernel) on this box -- measured here, not taken
+    from whichever parametrisation happens to run first (-k, xdist, reordering)"""
+    import torch
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+    cpu = native_build.LpiObca()
+    cl = closedLoop(problemSetting("demo1"), solver=cpu)
+    cl.N_free = 10
+    cl.mpc_openLoop_freeTime()
+    call = cpu.calls[-1]
+    s = BatchSolver(10, call["m"], max_batch=1)
+    args = (4, call["x0"][None], call["u0"][None], call["xref"][None], call["A"][None], call["b"][None], [call["Ts"]], call["term"][None],
+            SolverParams(xL=cl.xL[:2], xU=cl.xU[:2]))
+    s.solve(*args)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    out = s.solve(*args)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    cost = dt / max(int(out.iters[0]), 1) / 10
+    s.close()
+    return cost
 
 
 @pytest.mark.parametrize("demo,N", [("demo1", 10), ("demo1", 40), ("demo1", 74), ("demo9", 50), ("demo9", 66), ("demo9", 74), ("demo9", 10)])
-def test_long_horizon_free_time_solves(demo, N):
+def test_long_horizon_free_time_solves(demo, N, stage_cost_ref):
     """src/simulation.py:225-231: `mpc.N_free = 10 # np.size(a_start_path, 0)` -- 3.69 s at N = 10 and 136.7 s at N = 74
     on demo9.  Cold start, start/goal-only reference.  Beyond the LDS (N > 26) the plan runs on the four-wavefront kernel with
     its rows in an HBM workspace (obca_ipm_kernel_gm): every solve in well under a second (the same solve
@@ -134,9 +161,8 @@ def test_long_horizon_free_time_solves(demo, N):
     assert int(out.iters[0]) == it and int(out.status[0]) == st          # deterministic
     assert t_gpu < t_warm + 0.1 + 0.5 * t_warm, (t_gpu, t_warm)
     per_stage_iter = t_warm / max(it, 1) / N
-    _STAGE_COST.setdefault("ref", per_stage_iter if (demo, N) == ("demo1", 10) else None)
-    if _STAGE_COST["ref"]:
-        assert per_stage_iter < 4.0 * _STAGE_COST["ref"], (per_stage_iter, _STAGE_COST)
+    assert per_stage_iter < 4.0 * stage_cost_ref, (per_stage_iter, stage_cost_ref)
+    assert t_warm < ABS_CEILING_S[N], (t_warm, ABS_CEILING_S[N])
     if (demo, N) == ("demo9", 10):
         assert st == 2 and not cl.feas       # infeasible by construction, reported as such
         return

@@ -185,3 +185,35 @@ def test_full_size_properties():
     assert np.abs(x[ok, :, -1] - b["xref"][ok][:, :, -1]).max() < 1e-7    # terminal equality of obca_mpc4
     assert np.abs(u[ok, 0]).max() <= 0.6 + 1e-7 and np.abs(u[ok, 1]).max() <= np.pi / 6 + 1e-7
     assert (ts[ok] > 0).all()
+
+
+def test_headline_batch_against_the_independent_oracle():
+    """The product path (obca_solve_batch, compile-time-shape wave kernel) against an oracle that shares NOTHING with it: oracle/
+    ipopt_like.py -- IPOPT's published algorithm on the NLP as the reference poses it (hard equalities, slack bounds, restoration
+    phase), from the reference's literal zero start.  Seeded C2 instances of the headline workload: same status (feasible), Ts_opt to
+    2e-7 s, poses to 1e-6 m, objective to 1e-6 relative (tests/test_ipopt_like.py has the same check on the host build)."""
+    import os
+    from oracle import ipopt_like
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+    cores = os.cpu_count() or 1
+    B, N = 256, 5
+    idx = list(range(0, B, 2 if cores >= 64 else 16))               # 128 instances on the GPU box's host (2-3 s each), 16 on a small one
+    b = sc.make_batch(B, N)
+    s = BatchSolver(N, b["m"], max_batch=B)
+    out = s.solve(b["variant"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], SolverParams())
+    torch.cuda.synchronize()
+    st, xo, uo, ts, info = (getattr(out, k).cpu().numpy() for k in ("status", "xopt", "uopt", "ts_opt", "info"))
+    ref = ipopt_like.solve_c2_sample(B, N, idx, procs=min(cores, 64))
+    n_ok = 0
+    for i, (rst, rts, rf, rx, ru, nres) in zip(idx, ref):
+        assert st[i] in (0, 1)
+        if rst != ipopt_like.OK:
+            continue                                                  # (the oracle alone ending elsewhere is its own matter: counted below)
+        n_ok += 1
+        assert ts[i] == pytest.approx(rts, abs=2e-7), i
+        np.testing.assert_allclose(xo[i], rx, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(uo[i], ru, rtol=0, atol=1e-5)
+        assert info[i, 0] == pytest.approx(rf, rel=1e-6)
+    assert n_ok >= 0.95 * len(idx), (n_ok, len(idx))
+    s.close()

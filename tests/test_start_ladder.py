@@ -223,3 +223,49 @@ def test_an_exhausted_ladder_returns_the_most_informative_pass(nlp_golden, order
     assert r.status == 2 and np.array_equal(r.xopt, spec_alone[second].xopt) and r.start_index == 1
     r = ipm_dense.solve(p, dict(start_order=order, retry_iter=10))
     assert r.status == 2 and np.array_equal(r.xopt, spec_alone[first].xopt) and r.start_index == 0
+
+
+def test_second_level_of_the_dodge_rung_on_c5_world_667():
+    """csrc/obca_device.h: OBCA_DODGE_LEVEL2_MU (round 6; obca_mpc8 only).  C5 world 667, step 20: obca_mpc6 is screened out, obca_mpc8 ends at
+    an infeasible stationary point (one mu >= 0 row short by 8 mm) from x0, window, zeros and both dodge starts at mu = 1 -- the rollout
+    stopped there although SLSQP finds a feasible plan from the window moved to the right (profiles/r05_bench_classify_all.json named it).
+    The same dodge start at IPOPT's own mu_init 0.1 ends on that plan (f = 0.029957, SLSQP's 0.029955).  Numpy specification, dense C oracle
+    and structured core: the same answer; obca_mpc6 does not get the second level (its failure has an answer: obca_mpc8)."""
+    from oracle.obca_nlp import Problem
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.closed_loop import closedLoop
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
+    s = native_build.LpiObca()
+    cl = closedLoop(sc.make_world_c5(667, n_dyn=2), solver=s)
+    cl.N_free = cl.N_fix = 5
+    cl.closed_loop_mpc4()
+    assert cl.k > 20                                                         # (round 5: stopped at step 20)
+    # the obca_mpc8 call of step 20: the first one whose order and first dodge level all fail
+    sp = SolverParams()
+    hit = None
+    for q in s.calls:
+        if q["variant"] != 8 or q["status"] not in (0, 1):
+            continue
+        arrs = (8, 5, q["m"], q["x0"][None], q["u0"][None], q["xref"][None], q["A"][None], q["b"][None], [q["Ts"]], q["term"][None])
+        if native_build.lpi_solve(*arrs, c_oracle.default_params(dodge=False))["status"][0] == 2 and abs(q["x0"][0] - 17.3473) < 1e-3:
+            hit = (q, arrs)
+    assert hit is not None
+    q, arrs = hit
+    p = Problem(8, 5, q["m"], q["x0"], q["u0"], q["xref"], q["A"], q["b"], q["Ts"], sp.Q_fix, sp.R_fix[0], sp.R_fix[1], sp.P_fix,
+                sp.xL, sp.xU, sp.uL, sp.uU, sp.ego, sp.dmin)
+    for side in (-1.0, 1.0):                                                 # first level: neither side
+        r = ipm_dense._solve_once(p, dict(mu_init=ipm_dense.RESTART_MU, max_iter=350), x_start=ipm_dense.dodge_start(p, side))
+        assert r.status == ipm_dense.STATUS_INFEASIBLE and 5e-3 < r.elastic < 1e-2
+    r = ipm_dense.solve(p)
+    assert r.status == 0 and r.dodged and r.f == pytest.approx(0.029956, abs=3e-6)
+    c, g = c_oracle.solve_batch(*arrs, c_oracle.default_params()), native_build.lpi_solve(*arrs, c_oracle.default_params())
+    assert c["iters"][0] == r.iters                        # dense C oracle: the specification's iterates
+    for o, tol in ((c, 1e-8), (g, 1e-6)):                  # (structured core: other linear algebra, the failing passes take a few iterations more)
+        assert o["status"][0] == 0
+        np.testing.assert_allclose(o["xopt"][0], r.xopt, rtol=0, atol=tol)
+    # obca_mpc6 on the same inputs (a terminal set within reach, so that the rung is tried): two dodge passes, not four
+    p6 = (6,) + arrs[1:9] + (np.array([[q["x0"][0] + 2.0, 1.0, 9.0]]),)
+    o6a = native_build.lpi_solve(*p6, c_oracle.default_params())
+    o6b = native_build.lpi_solve(*p6, c_oracle.default_params(dodge=False))
+    o8b = native_build.lpi_solve(*arrs, c_oracle.default_params(dodge=False))
+    if o6a["status"][0] == 2:
+        assert o6a["iters"][0] - o6b["iters"][0] < g["iters"][0] - o8b["iters"][0]

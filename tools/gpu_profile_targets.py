@@ -4,6 +4,10 @@ Run under `rocprofv3 --kernel-trace --stats` or one `--pmc` pass at a time (tool
 import sys
 import numpy as np, torch
 sys.path.insert(0, '.')
+import os
+from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import _lib
+if os.environ.get("OBCA_LIB"):          # a dev build next to the product library (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.join(_lib.HERE, os.environ["OBCA_LIB"])
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
 from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
 

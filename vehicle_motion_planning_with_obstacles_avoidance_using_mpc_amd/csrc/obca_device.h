@@ -77,6 +77,14 @@
    detour of lateral offset d over a path of length L is about 2 d^2 / L longer, so below it no offset that clears anything fits -- and the
    closed loop's terminal set (x0 + 5 m, five steps of exactly 1 m) has 1e-9 m to spare while the car runs straight at full speed */
 #define OBCA_DODGE_MIN_SPARE 0.1
+/* Second level of the rung (round 6), obca_mpc8 only -- the variant with no fallback behind it (where it fails the reference's closed loop
+   stops, src/closed_loop.py:401-413): when neither side of the first level ends feasible, the same two starts again with IPOPT's own
+   initial barrier parameter OBCA_MU_INIT instead of OBCA_RESTART_MU.  The dodge starts are nearly feasible with active rows; a barrier
+   parameter of 1 pushes the first iterates far enough from them to fall back into the basin of the infeasible stationary point.  Seen
+   on C5 world 667 (step 20); then measured on 8192 worlds no rule of this build was looked at on: their only two solver failures
+   (worlds 7225, 11188) both end feasible with it (profiles/r06_c5_heldout_failures.json).  Passes of the rung: */
+#define OBCA_DODGE_LEVEL2_MU OBCA_MU_INIT
+#define OBCA_DODGE_PASSES(variant) ((variant) == 8 ? 4 : 2)
 /* transient, kernel-internal: a feasible answer of the first dodge pass waiting for the second one (never returned to a caller) */
 #define OBCA_STATUS_DODGE_OK 3
 #define OBCA_STATUS_DODGE_ACC 4

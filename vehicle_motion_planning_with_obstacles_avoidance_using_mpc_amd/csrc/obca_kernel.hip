@@ -1736,10 +1736,12 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         escalated = l0 & 15; held_bits = l0 & 0xf20;
         start_s = __builtin_amdgcn_readfirstlane(ladder_state[3]);
         if (A.variant[inst] == 4 && (l0 & 16) && escalated < OBCA_N_ESCALATIONS) ++escalated;
-        else { escalated = 0; if (++start_s >= Ain.prm.opt.nstarts + ((Ain.prm.opt.dodge && A.variant[inst] != 4) ? 2 : 0)) return; }
+        else { escalated = 0; if (++start_s >= Ain.prm.opt.nstarts + ((Ain.prm.opt.dodge && A.variant[inst] != 4) ? OBCA_DODGE_PASSES(A.variant[inst]) : 0)) return; }
     }
     const double rho_mult = escalated ? OBCA_RHO_ESCALATION(escalated) : 1.0;
-    const int kind = start_s < Ain.prm.opt.nstarts ? OBCA_START_KIND(order, start_s) : (start_s == Ain.prm.opt.nstarts ? OBCA_KIND_DODGE_R : OBCA_KIND_DODGE_L);
+    // (dodge passes nstarts .. nstarts + 3: right, left at OBCA_RESTART_MU, then -- obca_mpc8 only, OBCA_DODGE_PASSES -- right, left at OBCA_DODGE_LEVEL2_MU)
+    const int kind = start_s < Ain.prm.opt.nstarts ? OBCA_START_KIND(order, start_s) : (((start_s - Ain.prm.opt.nstarts) & 1) == 0 ? OBCA_KIND_DODGE_R : OBCA_KIND_DODGE_L);
+    const bool dodge2 = start_s >= Ain.prm.opt.nstarts + 2;
     const bool from_window = kind == OBCA_KIND_WINDOW;
 
     // ---- layout ------------------------------------------------------------------------------------
@@ -1933,7 +1935,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     SYNC();
     f0 = eval_objective<true>(L, S, in, S.x, sf, lane);
     PUT(IV_F, f0);
-    double mu = (from_window || kind >= OBCA_KIND_DODGE_R) ? OBCA_RESTART_MU : (warm ? A.warm_mu : OBCA_MU_INIT);
+    double mu = (from_window || (kind >= OBCA_KIND_DODGE_R && !dodge2)) ? OBCA_RESTART_MU : (warm ? A.warm_mu : (dodge2 ? OBCA_DODGE_LEVEL2_MU : OBCA_MU_INIT));
     // rows: bounds, slacks with bound push, elastic variables on their 1-d central path
     {
         int bb = 0;
@@ -2478,7 +2480,7 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
             if (lane == 0) ladder_state[0] = (l0 & 15) | (status == OBCA_STATUS_INFEASIBLE ? 16 : 0) | 32 | ((keep ? (status == OBCA_STATUS_INFEASIBLE ? ls + 1 : 0) : held_code) << 8);
         } else {
             const bool ok = status == OBCA_STATUS_OK || status == OBCA_STATUS_ACCEPTABLE;
-            if (ls == nst) {           // to the right: goes out if feasible, marked "one more pass to come"
+            if (((ls - nst) & 1) == 0) {   // to the right (either level): goes out if feasible, marked "one more pass to come"
                 keep = ok;
                 status_out = ok ? (status == OBCA_STATUS_OK ? OBCA_STATUS_DODGE_OK : OBCA_STATUS_DODGE_ACC) : -100;
                 if (ok && lane == 0) ladder_f = GET(IV_F) / sf;
