@@ -339,7 +339,7 @@ def start_order_leg(solver, dv, out0, B, order, steps=3):
             "same_optimum_as_the_default_order": int(same.sum().item()), "of_instances_both_solved": int(both.sum().item())}
 
 
-def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False, classify_max=None, start_order=0):
+def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=False, classify_max=None, start_order=0, dodge=True):
     """Config C5: B Monte-Carlo rollouts of the receding-horizon loop per GPU, harness and solves on the device
     (obca_rollouts_run: one persistent kernel, one wavefront per rollout); worlds first .. first+B-1, resident in HBM
     before the clock starts.  With a process group every rank runs the whole loop for its own worlds (no collective on
@@ -348,9 +348,9 @@ def closed_loop_c5(B, n_dyn=2, warm_start=None, first=0, dist=None, classify=Fal
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
     w = pack_worlds([sc.make_world_c5(first + i, n_dyn=n_dyn) for i in range(B)])
     prm = None
-    if start_order:
+    if start_order or not dodge:
         from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
-        prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), start_order=start_order)
+        prm = SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), start_order=start_order, dodge=dodge)
     dr = DeviceRollouts(w, N=5, warm_start=warm_start, params=prm)
     dr.run(1)
     torch.cuda.synchronize()
@@ -633,11 +633,19 @@ def main():
                 r = start_order_leg(solver, dv, out, B, "zeros")
                 r["note"] = "obca_params.start_order = OBCA_START_ZEROS_FIRST: the reference's literal all-zero start first (src/obca.py:856) -- the default of rounds 1-3, kept for comparison"
                 return r
+            def c5_dodge_off():
+                c5 = closed_loop_c5(args.closed_loop_rollouts, dodge=False)
+                r = {k: c5[k] for k in ("value", "unit", "seconds", "converged_steps", "attempted_steps", "rollouts_to_step_cap", "rollouts_stopped_infeasible", "mean_ipm_iters") if k in c5}
+                r["note"] = ("obca_params.dodge = off (NOT the default): the ladder's last rung costs C5 a third of its launch and rescues ~20 of 4096 rollouts -- the launch lasts as long "
+                             "as its longest ROLLOUT (a serial chain of <= 30 steps), and the rescued rollouts, which need the rung again at every later step, are the longest "
+                             "(profiles/r06_c5_dodge.txt); the rung stays on because the reference's own demo11 run needs it (DESIGN.md section 2)")
+                return r
             classify = cpu and args.full
             legs += [("config_c3", lambda: config_c3(B, classify=classify), True),
                      ("closed_loop", lambda: closed_loop_c5(args.closed_loop_rollouts, classify=cpu,
                                                             classify_max=None if args.classify_all else (48 if args.full else 16)), True),
                      ("x0_first", x0_first_all, True),
+                     ("closed_loop_dodge_off", c5_dodge_off, True),
                      ("open_loop", lambda: open_loop(classify=classify), True),
                      ("reference_gif", reference_gif_leg, True),
                      ("zeros_first", zeros_first, True),

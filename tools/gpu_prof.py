@@ -23,7 +23,7 @@ elif p[:,18].max() > 0:     # library built with -DOBCA_TWO_SIDED_CHECK: slots 1
     print('two-sided vs one-sided sweep, same data: max rel. difference of the step %.2e (median of per-instance maxima %.2e), of the elastic multiplier steps %.2e (median %.2e)'
           % (p[:,18].max()/1e18, np.median(p[:,18])/1e18, p[:,19].max()/1e18, np.median(p[:,19])/1e18))
     p[:,18:] = 0
-names=["grad+err","mu","rowE+gatherB","asm_stages","local","riccati","rowsteps","linesearch","accept","reeval","-","loop","r:FG+term","r:phaseA","r:phaseB","r:stage0","r:forward","r:recover","-","-"]
+names=["grad+err","mu","rowE+gatherB","asm_stages","local","riccati","rowsteps","linesearch","accept","reeval","prologue","loop","r:FG+term","r:phaseA","r:phaseB","r:stage0","r:forward","r:recover","-","-"]
 tot=p[:,:12].sum(1)
 print('mean iters %.1f nfact %.1f total cycles/solve %.3e'%(it.mean(), nf.mean(), tot.mean()))
 for i,n in enumerate(names):

@@ -1694,6 +1694,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
         }
     }
     if (inst >= A.B) return;
+#ifdef OBCA_PROFILE
+    const long long prof_body_t0 = wall_clock64();   // (prologue of a pass: descriptor, instance data, start point, scaling, row initialisation -> slot 10 of the one-wavefront kernels)
+#endif
     if (A.variant[inst] == 0) {                      // masked out by the caller (device-side closed loop)
         if (lane == 0) { A.status[inst] = OBCA_STATUS_SKIPPED; A.iters[inst] = 0; }
         return;
@@ -2028,6 +2031,9 @@ __device__ __forceinline__ void obca_ipm_body(DESC& Ain, const int inst, const b
     bool soc_pass = false, use_soc = false, first_trial = true;
     int soc_it = 0;
     PROF_DECL
+#ifdef OBCA_PROFILE
+    if (NT == 64) prof_t[10] += prof_last - prof_body_t0;
+#endif
     if (bad_bounds) status = OBCA_STATUS_BAD_BOUNDS;
     else
     for (it = 0; it <= max_iter; ++it) {
