@@ -29,7 +29,23 @@ ALG_BYTES = {(5, 6): 1320, (5, 12): 2184, (6, 6): 1528}       # SURVEY.md 8(d): 
 HBM_PEAK_GBPS = 8000.0                                          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+
+
+def _pmc_summary_file():
+    """the counter summary to report from: the newest profiles/r<NN>_pmc_summary.json taken on the kernel sources in the tree; if none
+    matches, the newest one (reported as stale, i.e. not at all)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")), reverse=True)
+    for f in files:
+        try:
+            with open(f) as fh:
+                if json.load(fh).get("kernel_source_hash") == kernel_source_hash():
+                    return f
+        except Exception:          # noqa: BLE001
+            continue
+    return files[0] if files else os.path.join(ROOT, "profiles", "none")
+
+
 VALU_LANE_RATE = 256 * 4 * 16 * 2.4e9        # lanes the VALUs of the chip issue per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12
 
 
@@ -50,7 +66,7 @@ def pmc_summary(kernel, B, N, M):
     (tools/pmc_summary.py turns the counter CSVs into this file).  None when no pass matches this workload; a pass taken on
     other kernel sources than the ones in the tree is returned with `stale` set and its figures are not reported."""
     try:
-        with open(PMC_SUMMARY) as f:
+        with open(_pmc_summary_file()) as f:
             doc = json.load(f)
     except Exception:
         return None
