@@ -106,7 +106,9 @@ typedef struct obca_params {
                                                    start from the window moved 3 m to the right and to the left of the direction of
                                                    travel (ramped in over three stages; lambda, mu on the separating half-space);
                                                    both run, the feasible answer with the lower objective is returned; their
-                                                   iterations are added to `iters`.  A failed rung leaves the answer the order's
+                                                   iterations are added to `iters`.  obca_mpc8 only (obca_mpc 0.6; its failure has no
+                                                   fallback behind it): if neither side ends feasible, the same two starts once more
+                                                   with IPOPT's own mu_init 0.1 instead of 1 (csrc/obca_device.h: OBCA_DODGE_LEVEL2_MU).  A failed rung leaves the answer the order's
                                                    starts left (see above).                                    */
     int32_t terminal_screen;           /* [on]    0 = the default (on), negative = off.  obca_mpc6 whose terminal set
                                                    x_N >= term[0] no trajectory can reach -- the first step's heading is x0's, the

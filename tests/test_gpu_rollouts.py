@@ -284,3 +284,39 @@ def test_terminal_screen_and_dodge_leave_the_closed_loop_words_or_say_why():
     assert np.array_equal(ref["iters"], outs["lockstep", True]["iters"]) and np.array_equal(outs["fused", False]["iters"], outs["lockstep", False]["iters"])
     it_on, it_off = int(ref["iters"].sum()), int(outs["fused", False]["iters"].sum())
     assert it_on < 0.9 * it_off, (it_on, it_off)
+
+
+def test_second_dodge_level_keeps_rollouts_alive_on_device_as_on_the_host():
+    """csrc/obca_device.h: OBCA_DODGE_LEVEL2_MU.  C5 worlds 667 (named as a solver failure in round 5's bench line, step 20), 7225 and 11188
+    (the only solver failures of 8192 held-out worlds, profiles/r06_c5_heldout_failures.json): obca_mpc8 ends feasible through the second
+    level of the dodge rung, the rollouts go on -- fused kernel, lock-step launches and the host build of the harness agree on every step;
+    with the rung off they stop where round 5 stopped."""
+    import torch
+    from oracle import c_oracle
+    from tests import native_build
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.rollouts import DeviceRollouts, pack_worlds
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.scenarios import make_world_c5
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import SolverParams
+    ids, stop_r5 = [667, 7225, 11188], [20, 16, 13]
+    worlds = [make_world_c5(i, n_dyn=2) for i in ids]
+    res = []
+    for mode in ("fused", "lockstep"):
+        dr = DeviceRollouts(pack_worlds(worlds), N=5)
+        dr.set_mode(mode)
+        dr.run(30)
+        torch.cuda.synchronize()
+        res.append({k: v.cpu().numpy() for k, v in dr.read().items()})
+    for k in ("steps", "flags", "variant", "status", "x_closed", "T_closed"):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    host = native_build.rollout_run(pack_worlds(worlds), 5, c_oracle.default_params(), 30)
+    for j, b in enumerate(ids):
+        k = int(res[0]["steps"][j])
+        assert k > stop_r5[j] and host["steps"][j] == k, (b, k, host["steps"][j])
+        assert res[0]["variant"][j, stop_r5[j]] == 8 and res[0]["status"][j, stop_r5[j]] in (0, 1)
+        np.testing.assert_allclose(res[0]["x_closed"][j, :k + 1], host["x_closed"][j, :k + 1], rtol=0, atol=1e-6)
+    w = pack_worlds(worlds)
+    dr = DeviceRollouts(w, N=5, params=SolverParams(xL=getattr(w, "xL", (0.0, 0.0)), xU=getattr(w, "xU", (39.0, 10.0)), dodge=False))
+    dr.run(30)
+    torch.cuda.synchronize()
+    off = {k: v.cpu().numpy() for k, v in dr.read().items()}
+    assert off["steps"].tolist() == stop_r5 and (off["flags"] == 3).all()
