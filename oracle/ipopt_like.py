@@ -495,18 +495,20 @@ def _solve_c2_instance(job):
     """worker of solve_c2_sample: (seeded C2 batch size B, horizon N, instance index) -> (status, Ts_opt, f, xopt, uopt, restorations)"""
     import warnings
     warnings.filterwarnings("ignore", category=RuntimeWarning)
-    B, N, i = job
+    B, N, i = job[:3]
+    gen = job[3] if len(job) > 3 else "c2"
     from tests import kkt_check
     from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
-    p = kkt_check.problem_of(sc.make_batch(B, N), i, N)
-    r = solve(p)
+    p = kkt_check.problem_of(sc.make_batch(B, N) if gen == "c2" else sc.make_batch_c3(B, N, gated=(gen == "c3gated")), i, N)
+    r = solve(p, opts=dict(max_iter=job[4]) if len(job) > 4 and job[4] else None)
     return int(r.status), float(r.Ts_opt), float(r.f), r.xopt, r.uopt, int(r.restorations)
 
 
-def solve_c2_sample(B, N, idx, procs=1):
-    """instances `idx` of the seeded C2 batch (scenarios.make_batch(B, N)) by this file's method from the reference's zero start, in
-    `procs` spawned processes (never a fork of a process that may hold a HIP context); returns the list of _solve_c2_instance tuples"""
-    jobs = [(B, N, int(i)) for i in idx]
+def solve_c2_sample(B, N, idx, procs=1, gen="c2", max_iter=None):
+    """instances `idx` of the seeded C2 batch (scenarios.make_batch(B, N); gen = "c3free": the free-time half of C3, make_batch_c3(B, N,
+    gated=False); "c3gated": its gated half, obca_mpc6) by this file's method from the reference's zero start, in `procs` spawned processes (never a fork of a process that may
+    hold a HIP context); returns the list of _solve_c2_instance tuples"""
+    jobs = [(B, N, int(i), gen, max_iter) for i in idx]
     if procs <= 1:
         return [_solve_c2_instance(j) for j in jobs]
     import multiprocessing as mp
