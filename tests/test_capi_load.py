@@ -91,3 +91,17 @@ def test_ctypes_mirror_of_obca_params_matches_the_header(lib, tmp_path):
     lib.obca_params_init(ctypes.byref(p))
     assert p.struct_size == nums[0] and bytes(p)[4:] == bytes(nums[0] - 4)
     assert bytes(_lib.ObcaParams()) == bytes(p)
+
+
+def test_committed_counter_summary_matches_the_kernel_sources():
+    """bench.py reports roofline.traffic / valu_issue_frac only from a profiles/r<NN>_pmc_summary.json whose kernel-source hash is the
+    tree's (tools/pmc_summary.py writes the hash of the sources the rocprofv3 --pmc passes measured): the newest matching file is
+    picked, and the committed tree has one -- a kernel change without a fresh `tools/profile.sh` run shows up here, not as a silent
+    `traffic: null` in the driver's bench line"""
+    import os
+    import bench
+    f = bench._pmc_summary_file()
+    assert os.path.exists(f)
+    r = bench.pmc_summary("obca_ipm_kernel_s5_3_6", 8192, 5, 6)
+    assert r is not None and not r["stale"], (f, r and r.get("source_hash"), bench.kernel_source_hash())
+    assert 10.8e6 < r["traffic_bytes"] < 1.4 * 10.81e6                 # 1320 B x 8192 algorithmic; measured 13.2 MB
