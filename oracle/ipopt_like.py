@@ -524,3 +524,34 @@ def solve_c2_sample(B, N, idx, procs=1, gen="c2", max_iter=None):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def _solve_packed_call(job):
+    """worker of solve_calls: one recorded closed-loop call (variant, N, m, x0, u0, xref, A, b, Ts, term, weights / bounds as SolverParams
+    fields) by this file's method from the zero start -> (status, f, xopt, Ts_opt, restorations)"""
+    import warnings
+    warnings.filterwarnings("ignore", category=RuntimeWarning)
+    from oracle.obca_nlp import Problem
+    v, N, q, W, box, max_iter = job
+    p = Problem(v, N, q["m"], q["x0"], q["u0"], q["xref"], q["A"], q["b"], q["Ts"], W[0], W[1][0], W[1][1], W[2], *box, term=q["term"] if v == 6 else None)
+    r = solve(p, opts=dict(max_iter=max_iter) if max_iter else None)
+    return int(r.status), float(r.f), r.xopt, float(r.Ts_opt), int(r.restorations)
+
+
+def solve_calls(jobs, procs=1):
+    """recorded calls (tuples as _solve_packed_call takes them) in `procs` spawned processes"""
+    if procs <= 1:
+        return [_solve_packed_call(j) for j in jobs]
+    import multiprocessing as mp
+    import os
+    env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS")}
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    try:
+        with mp.get_context("spawn").Pool(min(procs, len(jobs))) as pool:
+            return pool.map(_solve_packed_call, jobs)
+    finally:
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
