@@ -1611,11 +1611,14 @@ LPI_FN void run_instance(const ObcaLaunch& A, double* ws, size_t stride, size_t 
     if (O0.dodge && !L.free_T && shortfall < -OBCA_DODGE_MIN_SPARE && !(o.status == OBCA_STATUS_OK || o.status == OBCA_STATUS_ACCEPTABLE || o.status == OBCA_STATUS_BAD_BOUNDS)) {
         bool dodged = false;
         double fbest = 0.0;
-        // (second level, obca_mpc8 only -- csrc/obca_device.h: OBCA_DODGE_PASSES: the same two starts at OBCA_DODGE_LEVEL2_MU, if the first found nothing)
+    #ifndef OBCA_DODGE_LEVEL1_MU          /* study knob of the HOST build only (tools/dodge_mu_study.py): the first level's barrier parameter; the kernels use OBCA_RESTART_MU */
+#define OBCA_DODGE_LEVEL1_MU OBCA_RESTART_MU
+#endif
+    // (second level, obca_mpc8 only -- csrc/obca_device.h: OBCA_DODGE_PASSES: the same two starts at OBCA_DODGE_LEVEL2_MU, if the first found nothing)
         for (int pass = 0; pass < OBCA_DODGE_PASSES(L.variant); ++pass) {
             if (pass == 2 && dodged) break;
             const int side = pass & 1;
-            const Out r = solve_instance(L, S, in, O0, nullptr, pass < 2 ? OBCA_RESTART_MU : OBCA_DODGE_LEVEL2_MU, side == 0 ? OBCA_KIND_DODGE_R : OBCA_KIND_DODGE_L, O0.retry_iter);
+            const Out r = solve_instance(L, S, in, O0, nullptr, pass < 2 ? OBCA_DODGE_LEVEL1_MU : OBCA_DODGE_LEVEL2_MU, side == 0 ? OBCA_KIND_DODGE_R : OBCA_KIND_DODGE_L, O0.retry_iter);
             iters += r.iters; nfact += r.nfact;
             const bool ok = r.status == OBCA_STATUS_OK || r.status == OBCA_STATUS_ACCEPTABLE;
             if (ok && (!dodged || r.f < fbest)) { store(r); dodged = true; fbest = r.f; }
