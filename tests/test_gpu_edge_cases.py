@@ -262,3 +262,36 @@ def test_auto_mode_picks_the_hbm_workspace_kernel_beyond_the_lds():
     assert ok_a.mean() > 0.9 and (ok_a != ok_l).sum() <= 2
     same = ok_a & ok_l & (res[None][2] == res["lane"][2])
     assert same.sum() >= 0.3 * B and np.abs(res[None][0] - res["lane"][0])[same].max() < 1e-7
+
+
+def test_workspace_allocation_failure_falls_back_to_the_lds_kernel(monkeypatch):
+    """csrc/obca_capi.hip (advisor, round 5): a shape auto mode sends to the one-wavefront HBM-workspace kernel (C3 free-time, N = 12, three
+    obstacles) on a handle whose workspace cannot be allocated: auto mode runs the LDS-resident four-wavefront kernel instead of returning
+    OBCA_E_NOMEM -- the same words as that kernel asked for by name -- and keeps doing so; an explicit workspace mode reports the failure."""
+    import torch
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd import scenarios as sc
+    from vehicle_motion_planning_with_obstacles_avoidance_using_mpc_amd.solver import BatchSolver, SolverParams
+    B, N = 16, 12
+    b = sc.make_batch_c3(B, N, gated=False)
+    args = (b["variant"], b["x0"], b["u0"], b["xref"], b["A"], b["b"], b["Ts"], b["term"], SolverParams())
+    ref = BatchSolver(N, b["m"], max_batch=B, mode="multiwave")
+    want = ref.solve(*args)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("OBCA_FAIL_WORKSPACE_ALLOC", "1")
+    s = BatchSolver(N, b["m"], max_batch=B)
+    for _ in range(2):
+        out = s.solve(*args)
+        torch.cuda.synchronize()
+        for k in ("xopt", "uopt", "ts_opt", "status", "iters"):
+            assert torch.equal(getattr(out, k), getattr(want, k)), k
+    s.close()
+    s = BatchSolver(N, b["m"], max_batch=B, mode="global1")
+    with pytest.raises(RuntimeError):
+        s.solve(*args)
+    s.close()
+    monkeypatch.delenv("OBCA_FAIL_WORKSPACE_ALLOC")
+    s = BatchSolver(N, b["m"], max_batch=B)                 # without the failure: the workspace kernel, same optimum
+    out = s.solve(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(out.status, want.status) and torch.allclose(out.xopt, want.xopt, rtol=0, atol=1e-6)
+    s.close(); ref.close()

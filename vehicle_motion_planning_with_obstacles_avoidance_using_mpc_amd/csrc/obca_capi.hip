@@ -361,7 +361,10 @@ extern "C" int obca_solve_batch(obca_handle* h, const int32_t* variant, int32_t 
     if (h->mode == 4 || h->mode == 5 || auto_gm1(h) || (h->mode == 0 && !h->wave_ok && !h->mw_ok && h->gm_ok)) {
         // shapes beyond the LDS: four wavefronts per instance, rows and O(rows) arrays in the handle's HBM workspace
         if (!h->gm_ok) return OBCA_E_LDS;
-        if (!h->gm_ws && hipMalloc(&h->gm_ws, sizeof(double) * (size_t)h->gm_doubles * (size_t)h->dims.max_batch) != hipSuccess) {
+        // (OBCA_FAIL_WORKSPACE_ALLOC in the environment: the allocation is treated as failed -- the only way to exercise the branch below
+        // on a 288 GB device; tests/test_gpu_edge_cases.py)
+        if (!h->gm_ws && (getenv("OBCA_FAIL_WORKSPACE_ALLOC") != nullptr ||
+                          hipMalloc(&h->gm_ws, sizeof(double) * (size_t)h->gm_doubles * (size_t)h->dims.max_batch) != hipSuccess)) {
             (void)hipGetLastError();
             h->gm_ws = nullptr;
             // auto mode with an LDS-resident alternative: run that instead of failing the call (it needs no workspace); an explicit
